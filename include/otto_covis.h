@@ -1,0 +1,147 @@
+/*
+ * otto_covis.h -- C-ABI of the MI355X covisitation-matrix builder.
+ *
+ * What this replaces in the reference: NOTHING the reference ships as code -- the
+ * builder that writes DATA/covisitation/<mode>/top_15_<kind>_<i>.pqt is absent
+ * (SURVEY.md F1).  The entry points below are what a maintainer's ctypes stub in
+ * a new src/covisitation/<builder>.py binds; their output feeds,
+ * unchanged, the consumers
+ *     src/covisitation/inference.py:19-35,87-111,282-308   (covisitation_df_to_dict)
+ *     src/ranker/regular_candidate_generation.py:75-101,270-296
+ *     src/ranker/covisitation_candidate_generation.py:49-73,201-227
+ * The only in-reference relative of the arithmetic is the session self-join of
+ *     src/matrix_factorization/torch_trainer.py:198-223.
+ * Semantics: SPEC-COVIS in DESIGN.md (restating SURVEY.md App. A).
+ *
+ * Conventions (SURVEY.md section 8 b): every function returns 0 or a negative
+ * OTTO_E* code and sets otto_last_error(); the caller owns every buffer it passes
+ * in; all pointers named d_* are DEVICE pointers (hipMalloc / torch CUDA tensors);
+ * all work is enqueued on the caller's hipStream_t (passed as void*); one context
+ * per device, not thread-safe; no exceptions or Python objects cross the ABI.
+ */
+#ifndef OTTO_COVIS_H
+#define OTTO_COVIS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OTTO_OK 0
+#define OTTO_EINVAL (-22)
+#define OTTO_ENOMEM (-12)
+#define OTTO_EHIP (-5)
+#define OTTO_ESTATE (-1)
+
+#define OTTO_COVIS_MAX_WINDOW 32
+#define OTTO_COVIS_MAX_FILTERS 4
+#define OTTO_COVIS_MAX_TYPE_WEIGHTS 4
+#define OTTO_COVIS_MAX_AIDS (1u << 26)
+
+/* kind groups: one pass over the expanded pairs reduces every kind of a group */
+#define OTTO_COVIS_GROUP_TYPE 0   /* type-weighted kinds: W = 65536 * sum Wk[type_y]        */
+#define OTTO_COVIS_GROUP_FILTER 1 /* pair-filter kinds:   W = 65536 * #sessions with a pair */
+#define OTTO_COVIS_GROUP_TIME 2   /* time_weighted:       W = sum 65536 + 3*65536*(ts_x-t0)/(t1-t0) */
+
+typedef struct otto_covis_params {
+    int32_t window;        /* tail window W (SPEC-COVIS 2), 2..32                       */
+    int32_t max_gap;       /* |ts_x - ts_y| <= max_gap seconds (SPEC-COVIS 3)           */
+    uint32_t n_aids;       /* aids are 0..n_aids-1, n_aids <= 2^26                      */
+    int32_t ts_min;        /* t0 of the time weight (global over ALL chunks / ranks)    */
+    int32_t ts_max;        /* t1                                                        */
+    int32_t want_time;     /* !=0: keep the time-weight channel (needed for GROUP_TIME) */
+    int32_t n_filters;     /* 0..4 pair-filter kinds                                    */
+    uint16_t filter_mask[OTTO_COVIS_MAX_FILTERS];              /* bit (type_x*3+type_y) */
+    int32_t n_type_weights;                                    /* 0..4 type-weighted kinds */
+    int32_t type_weight[OTTO_COVIS_MAX_TYPE_WEIGHTS][3];       /* Wk[type_y] > 0        */
+} otto_covis_params;
+
+typedef struct otto_covis_ctx otto_covis_ctx;
+
+/* statistics filled by otto_covis_stats (all int64) */
+enum {
+    OTTO_COVIS_STAT_SESSIONS = 0,   /* sessions fed                                      */
+    OTTO_COVIS_STAT_TAIL_EVENTS,    /* events inside tail windows (= run slots)          */
+    OTTO_COVIS_STAT_PAIR_SLOTS,     /* reserved record slots  sum n(n-1)                 */
+    OTTO_COVIS_STAT_PAIRS,          /* P: deduped ordered pairs expanded (valid after index) */
+    OTTO_COVIS_STAT_RUNS,           /* non-empty (window, aid_x) runs                    */
+    OTTO_COVIS_STAT_ITEMS_S,
+    OTTO_COVIS_STAT_ITEMS_M,
+    OTTO_COVIS_STAT_ITEMS_L,
+    OTTO_COVIS_STAT_RETRIES,        /* overflow re-partition rounds since the index was built */
+    OTTO_COVIS_STAT_COUNT
+};
+
+const char* otto_last_error(void);
+
+int otto_covis_create(otto_covis_ctx** ctx, const otto_covis_params* params);
+void otto_covis_destroy(otto_covis_ctx* ctx);
+
+/* Forget every fed chunk (keeps the workspace allocations). */
+int otto_covis_reset(otto_covis_ctx* ctx);
+
+/*
+ * K1 pair-expand over one chunk of sessions.  Events of session s are
+ * d_aid/d_ts/d_type[d_sess_off[s] .. d_sess_off[s+1]) sorted by ts.  May be called
+ * several times (session chunks); records accumulate in the context.
+ * Synchronises the stream once (to size the record buffers).
+ */
+int otto_covis_feed(otto_covis_ctx* ctx, const uint32_t* d_aid, const int32_t* d_ts, const uint8_t* d_type,
+                    const int64_t* d_sess_off, int64_t n_sess, void* stream);
+
+/*
+ * Group the expanded pairs by aid_x, reduce and select: for every kind j of
+ * `group` and every aid_x the top-k aid_y by (W desc, aid_y asc).
+ *   d_out_y [n_kinds][n_aids][k]  uint32   aid_y, rank order
+ *   d_out_w [n_kinds][n_aids][k]  uint64   Q16 weight W (wgt = W / 65536)
+ *   d_out_n [n_kinds][n_aids]     int32    valid entries (0..k)
+ * n_kinds = n_type_weights / n_filters / 1 for GROUP_TYPE / FILTER / TIME.
+ * Synchronises the stream (overflow check; exactness is unconditional).
+ */
+int otto_covis_finalize(otto_covis_ctx* ctx, int group, int k, uint32_t* d_out_y, uint64_t* d_out_w,
+                        int32_t* d_out_n, void* stream);
+
+int otto_covis_stats(otto_covis_ctx* ctx, int64_t* out /* [OTTO_COVIS_STAT_COUNT] */);
+
+/* Tuning knobs; results are exact for every value.
+ *   "l_cap": expanded pairs per hash partition of a heavy aid_x (default 6144). */
+int otto_covis_set_option(otto_covis_ctx* ctx, const char* name, int64_t value);
+
+/*
+ * Multi-GPU exchange (SURVEY.md section 8 e): the expanded runs whose aid_x lies in
+ * [x_lo, x_hi) leave as  d_hdr[2*n_runs] = {aid_x, len}*,  d_rec[n_recs] (records of the
+ * runs back to back) and, when want_time, d_tw[n_recs]; the aid_x owner appends them with
+ * otto_covis_import_runs.  export_count sizes the buffers (synchronises the stream).
+ */
+int otto_covis_export_count(otto_covis_ctx* ctx, uint32_t x_lo, uint32_t x_hi, int64_t* n_runs, int64_t* n_recs,
+                            void* stream);
+int otto_covis_export_runs(otto_covis_ctx* ctx, uint32_t x_lo, uint32_t x_hi, uint32_t* d_hdr, uint32_t* d_rec,
+                           uint32_t* d_tw, void* stream);
+int otto_covis_import_runs(otto_covis_ctx* ctx, const uint32_t* d_hdr, int64_t n_runs, const uint32_t* d_rec,
+                           const uint32_t* d_tw, int64_t n_recs, void* stream);
+
+/* Test hook: copy the raw K1 output to HOST buffers (any pointer may be NULL).
+ * h_rec/h_tw: [PAIR_SLOTS] uint32, h_run_x: [TAIL_EVENTS] uint32, h_run_desc: [TAIL_EVENTS] uint64
+ * (desc = slot_offset << 8 | len). rec = aid_y | type_y << 26 | filter_bits << 28. */
+int otto_covis_copy_records(otto_covis_ctx* ctx, uint32_t* h_rec, uint32_t* h_tw, uint32_t* h_run_x,
+                            uint64_t* h_run_desc);
+
+/* per-kernel device time of the last feed/finalize in milliseconds (hipEvents on the
+ * caller's stream), order: see OTTO_COVIS_T_* ; returns count written. */
+enum {
+    OTTO_COVIS_T_WINSCAN = 0,
+    OTTO_COVIS_T_EXPAND,     /* K1 pair-expand            */
+    OTTO_COVIS_T_INDEX,      /* histogram + scan + scatter + item lists */
+    OTTO_COVIS_T_REDUCE_S,
+    OTTO_COVIS_T_REDUCE_M,
+    OTTO_COVIS_T_REDUCE_L,
+    OTTO_COVIS_T_MERGE,
+    OTTO_COVIS_T_COUNT
+};
+int otto_covis_timings(otto_covis_ctx* ctx, float* out_ms /* [OTTO_COVIS_T_COUNT] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,102 @@
+"""ctypes binding of ``csrc/libotto_amd.so`` (the C-ABI declared in ``include/*.h``).
+
+The product path has NO CPU fallback: if the HIP library is missing or a symbol is
+absent this module raises at first use, and every entry point raises
+``OttoError`` with ``otto_last_error()`` on a non-zero return code.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libotto_amd.so')
+
+MAX_FILTERS = 4
+MAX_TYPE_WEIGHTS = 4
+GROUP_TYPE, GROUP_FILTER, GROUP_TIME = 0, 1, 2
+STAT_NAMES = ('sessions', 'tail_events', 'pair_slots', 'pairs', 'runs', 'items_s', 'items_m', 'items_l', 'retries')
+TIMING_NAMES = ('winscan', 'expand', 'index', 'reduce_s', 'reduce_m', 'reduce_l', 'merge')
+
+
+class OttoError(RuntimeError):
+    pass
+
+
+class CovisParams(C.Structure):
+    # mirrors otto_covis_params (include/otto_covis.h)
+    _fields_ = [
+        ('window', C.c_int32),
+        ('max_gap', C.c_int32),
+        ('n_aids', C.c_uint32),
+        ('ts_min', C.c_int32),
+        ('ts_max', C.c_int32),
+        ('want_time', C.c_int32),
+        ('n_filters', C.c_int32),
+        ('filter_mask', C.c_uint16 * MAX_FILTERS),
+        ('n_type_weights', C.c_int32),
+        ('type_weight', (C.c_int32 * 3) * MAX_TYPE_WEIGHTS),
+    ]
+
+
+_vp, _i64, _i32, _u32 = C.c_void_p, C.c_int64, C.c_int, C.c_uint32
+_p_i64 = C.POINTER(C.c_int64)
+
+# every symbol include/*.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    # include/otto_covis.h
+    'otto_last_error': (C.c_char_p, []),
+    'otto_covis_create': (_i32, [C.POINTER(_vp), C.POINTER(CovisParams)]),
+    'otto_covis_destroy': (None, [_vp]),
+    'otto_covis_reset': (_i32, [_vp]),
+    'otto_covis_feed': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'otto_covis_finalize': (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    'otto_covis_stats': (_i32, [_vp, _p_i64]),
+    'otto_covis_set_option': (_i32, [_vp, C.c_char_p, _i64]),
+    'otto_covis_export_count': (_i32, [_vp, _u32, _u32, _p_i64, _p_i64, _vp]),
+    'otto_covis_export_runs': (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    'otto_covis_import_runs': (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _vp]),
+    'otto_covis_copy_records': (_i32, [_vp, _vp, _vp, _vp, _vp]),
+    'otto_covis_timings': (_i32, [_vp, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def register(signatures):
+    """Let sibling modules (matrix_factorization) add their header's symbols."""
+    SIGNATURES.update(signatures)
+    global _lib
+    if _lib is not None:
+        _bind(_lib, signatures)
+
+
+def _bind(lib, signatures):
+    for name, (res, args) in signatures.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise OttoError(f'{LIB_PATH} does not export {name}; rebuild with __graft_entry__.build()') from e
+        fn.restype = res
+        fn.argtypes = args
+
+
+def lib():
+    """Load (once) and return the shared library; raises OttoError when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OttoError(
+                f'HIP library {LIB_PATH} is not built. Run `python -c "import __graft_entry__ as g; g.build()"` '
+                f'(or `make -C {os.path.dirname(LIB_PATH)}`). There is no CPU fallback.')
+        try:
+            loaded = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise OttoError(f'cannot load {LIB_PATH}: {e}') from e
+        _bind(loaded, SIGNATURES)
+        _lib = loaded
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().otto_last_error()
+        raise OttoError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')

@@ -1,0 +1,1070 @@
+// Covisitation-matrix builder for MI355X (gfx950): pair-expand -> inverted run index
+// -> per-aid LDS hash reduce + top-k.  C-ABI in include/otto_covis.h; semantics =
+// SPEC-COVIS (restating SURVEY.md App. A).  The reference has no builder
+// (SURVEY.md F1); the only related reference code is the session self-join of
+// src/matrix_factorization/torch_trainer.py:198-223.
+//
+// Pipeline (DESIGN.md "Covisitation kernels"):
+//   winscan  : per session n = min(len, W); exclusive scans of n(n-1) (record slots) and n (run slots)
+//   K1 expand: one 32-lane half-wave per session window; class ids, LDS atomicMin matrix
+//              M[class_x][class_y] = first valid (i,j); emit one 4-byte record per deduped pair,
+//              grouped by aid_x inside the window (a "run"), plus one run descriptor per window event
+//   index    : histogram of runs per aid_x (one 64-bit atomic per run), scan, scatter of run descriptors,
+//              work-item lists in three size bins (S/M/L; L items are hash partitions of one heavy aid_x)
+//   K2 reduce: per work item gather the runs' records, aggregate by aid_y in an LDS hash table
+//              (no global atomics), then block-wide top-k per kind; heavy aids: partial top-k per
+//              partition + exact merge
+#include "common.h"
+#include "../../include/otto_covis.h"
+
+#include <stdarg.h>
+#include <string.h>
+#include <vector>
+
+namespace otto {
+
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+// ---------------------------------------------------------------------------
+// generic 3-phase exclusive scan of f(i), i in [0, n): out[i] = sum_{j<i} f(j), out[n] = total
+// ---------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 1024;
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+template <typename F>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_sum(F f, int64_t n, uint64_t* partial) {
+    __shared__ uint64_t sm[SCAN_THREADS / 64 + 1];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t v = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) v += f(base + k);
+    uint64_t tot;
+    (void)block_excl_scan<uint64_t, SCAN_THREADS>(v, sm, &tot);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_partials(uint64_t* partial, int nb) {
+    __shared__ uint64_t sm[SCAN_THREADS / 64 + 1];
+    uint64_t run = 0;
+    for (int b0 = 0; b0 < nb; b0 += SCAN_THREADS) {
+        int i = b0 + threadIdx.x;
+        uint64_t v = i < nb ? partial[i] : 0;
+        uint64_t tot;
+        uint64_t ex = block_excl_scan<uint64_t, SCAN_THREADS>(v, sm, &tot);
+        if (i < nb) partial[i] = run + ex;
+        run += tot;
+    }
+    if (threadIdx.x == 0) partial[nb] = run;
+}
+
+template <typename F>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_write(F f, int64_t n, const uint64_t* partial, int nb,
+                                                              uint64_t* out) {
+    __shared__ uint64_t sm[SCAN_THREADS / 64 + 1];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t x[SCAN_ITEMS];
+    uint64_t v = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        x[k] = (base + k < n) ? f(base + k) : 0;
+        v += x[k];
+    }
+    uint64_t tot;
+    uint64_t ex = block_excl_scan<uint64_t, SCAN_THREADS>(v, sm, &tot) + partial[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = ex;
+        ex += x[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = partial[nb];
+}
+
+// out must hold n+1 entries, partial ceil(n/TILE)+1 entries.
+template <typename F>
+static int device_scan(F f, int64_t n, uint64_t* out, uint64_t* partial, hipStream_t s) {
+    int nb = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+    if (nb == 0) {
+        OTTO_HIP(hipMemsetAsync(out, 0, sizeof(uint64_t), s));
+        return 0;
+    }
+    k_scan_sum<F><<<nb, SCAN_THREADS, 0, s>>>(f, n, partial);
+    k_scan_partials<<<1, SCAN_THREADS, 0, s>>>(partial, nb);
+    k_scan_write<F><<<nb, SCAN_THREADS, 0, s>>>(f, n, partial, nb, out);
+    OTTO_HIP(hipGetLastError());
+    return 0;
+}
+static size_t scan_partial_bytes(int64_t n) { return ((size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 1) * sizeof(uint64_t); }
+
+// ---------------------------------------------------------------------------
+// winscan functors
+// ---------------------------------------------------------------------------
+struct WinPairs {   // n(n-1) record slots of session i
+    const int64_t* off;
+    int W;
+    __device__ uint64_t operator()(int64_t i) const {
+        int64_t n = off[i + 1] - off[i];
+        n = n < W ? n : W;
+        return n >= 2 ? (uint64_t)(n * (n - 1)) : 0;
+    }
+};
+struct WinEvents {  // n run slots of session i
+    const int64_t* off;
+    int W;
+    __device__ uint64_t operator()(int64_t i) const {
+        int64_t n = off[i + 1] - off[i];
+        n = n < W ? n : W;
+        return n >= 2 ? (uint64_t)n : 0;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// K1: pair-expand
+// ---------------------------------------------------------------------------
+constexpr uint32_t M_EMPTY = 0xFFFFFFFFu;
+constexpr int REC_AID_BITS = 26;
+constexpr uint32_t REC_AID_MASK = (1u << REC_AID_BITS) - 1;
+constexpr int EXP_HW = 8;   // half-waves (= session windows) per 256-thread workgroup
+
+struct ExpandArgs {
+    const uint32_t* aid;
+    const int32_t* ts;
+    const uint8_t* type;
+    const int64_t* sess_off;
+    const uint64_t* pair_base;   // [S+1] chunk-local exclusive scans
+    const uint64_t* ev_base;
+    int64_t n_sess;
+    uint32_t* rec;
+    uint32_t* tw;
+    uint32_t* run_x;
+    uint64_t* run_desc;
+    uint64_t rec_base;           // first record / run slot of this chunk
+    uint64_t run_base;
+    int window;
+    int max_gap;
+    int64_t t0;
+    int64_t tspan;
+    uint32_t fmask[4];
+};
+
+template <bool TIME>
+__global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
+    __shared__ uint4 s_ev[EXP_HW][32];            // aid, ts, type | cls << 8, time extra
+    __shared__ uint32_t s_M[EXP_HW][32 * 32];     // first valid (i << 5 | j) per (class_x, class_y)
+    __shared__ uint32_t s_FB[EXP_HW][32 * 4];     // 4 filter bits per (class_x, class_y)
+
+    const int hw = threadIdx.x >> 5;
+    const int l = threadIdx.x & 31;
+    const unsigned half_shift = threadIdx.x & 32;
+    const int64_t stride = (int64_t)gridDim.x * EXP_HW;
+
+    for (int64_t s0 = (int64_t)blockIdx.x * EXP_HW; s0 < a.n_sess; s0 += stride) {
+        const int64_t s = s0 + hw;
+        int n = 0;
+        int64_t wstart = 0;
+        uint64_t pbase = 0, ebase = 0;
+        if (s < a.n_sess) {
+            int64_t lo = a.sess_off[s], hi = a.sess_off[s + 1];
+            int64_t len = hi - lo;
+            n = (int)(len < a.window ? len : a.window);
+            if (n < 2) n = 0;
+            wstart = hi - n;
+            pbase = a.pair_base[s];
+            ebase = a.ev_base[s];
+        }
+        // ---- phase A: load the window, class ids -------------------------------------------
+        uint32_t aid = 0xFFFFFFFFu, ty = 0, extra = 0;
+        int32_t t = 0;
+        if (l < n) {
+            aid = a.aid[wstart + l];
+            t = a.ts[wstart + l];
+            ty = a.type[wstart + l];
+            if (TIME) extra = a.tspan > 0 ? (uint32_t)((uint64_t)(196608ull * (uint64_t)((int64_t)t - a.t0)) / (uint64_t)a.tspan) : 0u;
+        }
+        s_ev[hw][l] = make_uint4(aid, (uint32_t)t, ty, extra);
+        __syncthreads();
+        int cls = l;
+        for (int j = n - 1; j >= 0; --j)
+            if (s_ev[hw][j].x == aid) cls = j;
+        if (l < n) {
+            s_ev[hw][l].z = ty | ((uint32_t)cls << 8);
+            s_FB[hw][l * 4 + 0] = 0; s_FB[hw][l * 4 + 1] = 0; s_FB[hw][l * 4 + 2] = 0; s_FB[hw][l * 4 + 3] = 0;
+        }
+        for (int r = 0; r < n; ++r) s_M[hw][r * 32 + l] = M_EMPTY;
+        __syncthreads();
+        // ---- phase B: every ordered pair (i, l); first valid pair per class pair -----------
+        if (l < n) {
+            for (int i = 0; i < n; ++i) {
+                const uint4 e = s_ev[hw][i];
+                int dt = (int)e.y - t;
+                dt = dt < 0 ? -dt : dt;
+                if (e.x != aid && dt <= a.max_gap) {
+                    const uint32_t ci = e.z >> 8, yi = e.z & 0xFFu;
+                    atomicMin(&s_M[hw][ci * 32 + cls], (uint32_t)((i << 5) | l));
+                    const uint32_t bit = yi * 3 + ty;
+                    const uint32_t fb = ((a.fmask[0] >> bit) & 1u) | (((a.fmask[1] >> bit) & 1u) << 1) |
+                                        (((a.fmask[2] >> bit) & 1u) << 2) | (((a.fmask[3] >> bit) & 1u) << 3);
+                    if (fb) atomicOr(&s_FB[hw][ci * 4 + (cls >> 3)], fb << ((cls & 7) * 4));
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase C: emit rows (runs) in class order ---------------------------------------
+        uint32_t off = 0, my_off = 0, my_cnt = 0;
+        for (int r = 0; r < n; ++r) {
+            const uint32_t e = (l < n) ? s_M[hw][r * 32 + l] : M_EMPTY;
+            const bool has = e != M_EMPTY;
+            const uint32_t hm = (uint32_t)(__ballot(has) >> half_shift);
+            const uint32_t cnt = __popc(hm);
+            if (has) {
+                const uint32_t rank = __popc(hm & ((1u << l) - 1u));
+                const uint32_t i = e >> 5, j = e & 31u;
+                const uint32_t tyj = s_ev[hw][j].z & 0xFFu;
+                const uint32_t fb = (s_FB[hw][r * 4 + (l >> 3)] >> ((l & 7) * 4)) & 0xFu;
+                const uint64_t slot = a.rec_base + pbase + off + rank;
+                a.rec[slot] = aid | (tyj << REC_AID_BITS) | (fb << 28);
+                if (TIME) a.tw[slot] = s_ev[hw][i].w;
+            }
+            if (l == r) { my_off = off; my_cnt = cnt; }
+            off += cnt;
+        }
+        if (l < n) {
+            a.run_x[a.run_base + ebase + l] = aid;
+            a.run_desc[a.run_base + ebase + l] = my_cnt ? (((a.rec_base + pbase + my_off) << 8) | my_cnt) : 0ull;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// index: histogram / scatter of runs by aid_x, work items
+// ---------------------------------------------------------------------------
+constexpr uint64_t CNT_REC_MASK = (1ull << 40) - 1;   // cnt64[x] = runs << 40 | records
+
+__global__ void k_hist_runs(const uint32_t* run_x, const uint64_t* run_desc, int64_t n_slots, uint64_t* cnt64,
+                            uint32_t n_aids) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t d = run_desc[i];
+        const uint64_t len = d & 0xFFull;
+        if (len) {
+            const uint32_t x = run_x[i];
+            if (x < n_aids) atomicAdd((unsigned long long*)&cnt64[x], (unsigned long long)((1ull << 40) | len));
+        }
+    }
+}
+
+struct RunCount {
+    const uint64_t* cnt64;
+    __device__ uint64_t operator()(int64_t x) const { return cnt64[x] >> 40; }
+};
+struct RecCount {
+    const uint64_t* cnt64;
+    __device__ uint64_t operator()(int64_t x) const { return cnt64[x] & CNT_REC_MASK; }
+};
+
+__global__ void k_scatter_runs(const uint32_t* run_x, const uint64_t* run_desc, int64_t n_slots,
+                               const uint64_t* run_start, uint32_t* cursor, uint64_t* sorted_desc, uint32_t n_aids) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t d = run_desc[i];
+        if (d & 0xFFull) {
+            const uint32_t x = run_x[i];
+            if (x < n_aids) {
+                const uint32_t c = atomicAdd(&cursor[x], 1u);
+                sorted_desc[run_start[x] + c] = d;
+            }
+        }
+    }
+}
+
+// size bins of the reduce kernel (table slots / threads / max records that are guaranteed to fit)
+constexpr int S_LOG2T = 9, S_THREADS = 64, S_CAP = 384;
+constexpr int M_LOG2T = 12, M_THREADS = 256, M_CAP = 3072;
+constexpr int L_LOG2T = 13, L_THREADS = 1024, L_CAP = 6144;
+
+__device__ __forceinline__ int l_log2r(uint64_t n, int boost, uint32_t l_cap) {
+    uint64_t parts = (n + l_cap - 1) / l_cap;
+    int lg = 0;
+    while ((1ull << lg) < parts) ++lg;
+    lg += boost;
+    const int maxlg = 32 - L_LOG2T;
+    return lg > maxlg ? maxlg : lg;
+}
+
+struct ItemCount {   // number of work items aid x contributes to bin `bin`
+    const uint64_t* cnt64;
+    const uint8_t* boost;
+    const uint32_t* flag;
+    int bin;
+    int only_flagged;
+    uint32_t l_cap;
+    __device__ uint64_t operator()(int64_t x) const {
+        const uint64_t n = cnt64[x] & CNT_REC_MASK;
+        if (n == 0) return 0;
+        if (only_flagged && !flag[x]) return 0;
+        const int b = n <= (uint64_t)S_CAP ? 0 : (n <= (uint64_t)M_CAP ? 1 : 2);
+        if (b != bin) return 0;
+        return bin == 2 ? (1ull << l_log2r(n, boost[x], l_cap)) : 1ull;
+    }
+};
+
+// item = x | part << 26 | log2R << 50
+__global__ void k_fill_items(ItemCount f, uint32_t n_aids, const uint64_t* item_start, uint64_t* items) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n_aids) return;
+    const uint64_t c = f((int64_t)x);
+    if (!c) return;
+    const uint64_t s = item_start[x];
+    uint64_t lg = 0;
+    while ((1ull << lg) < c) ++lg;
+    for (uint64_t p = 0; p < c; ++p) items[s + p] = (uint64_t)x | (p << 26) | (lg << 50);
+}
+
+// ---------------------------------------------------------------------------
+// K2: per-item LDS hash reduce + top-k
+// ---------------------------------------------------------------------------
+constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
+constexpr int MAX_K = 32;
+constexpr int MAX_KINDS = 4;
+
+struct ReduceArgs {
+    const uint64_t* items;
+    uint32_t n_items;
+    const uint64_t* cnt64;         // [n_aids] runs << 40 | records
+    const uint64_t* run_start;     // [n_aids+1]
+    const uint64_t* sorted_desc;
+    const uint32_t* rec;
+    const uint32_t* tw;
+    int group;
+    int nk;                        // kinds selected in this pass (<= MAX_KINDS)
+    int k;
+    int chan_shift;                // FILTER: first filter bit of this pass
+    uint32_t coef[MAX_KINDS][3];   // unit weight of kind j = sum_c v[c] * coef[j][c]
+    uint32_t n_aids;
+    int kind_base;                 // first output kind index of this pass
+    uint32_t* out_y;               // [kinds][n_aids][k]
+    uint64_t* out_w;
+    int32_t* out_n;                // [kinds][n_aids]
+    uint32_t* part_y;              // [item][nk][k] partial top-k of L items with R > 1
+    uint64_t* part_w;
+    uint32_t* flag;                // [n_aids] overflow -> redo with more partitions
+    uint8_t* boost;
+    uint32_t* ovf_count;
+    uint32_t* work_counter;
+    uint32_t l_cap;                // records per L partition the item lists were sized for
+};
+
+__device__ __forceinline__ bool cand_better(uint64_t w1, uint32_t y1, uint64_t w2, uint32_t y2) {
+    return w1 > w2 || (w1 == w2 && y1 < y2);
+}
+
+// Wave-wide sorted top list: lane i holds the i-th best (w == 0: empty). Push one candidate per lane.
+__device__ __forceinline__ void wave_topk_push(uint64_t& bw, uint32_t& by, uint64_t cw, uint32_t cy, int k) {
+    const unsigned l = lane_id();
+    uint64_t tw = __shfl(bw, k - 1, 64);
+    uint32_t tyy = __shfl(by, k - 1, 64);
+    uint64_t m = __ballot(cw != 0 && cand_better(cw, cy, tw, tyy));
+    while (m) {
+        const int src = __ffsll((unsigned long long)m) - 1;
+        const uint64_t w = __shfl(cw, src, 64);
+        const uint32_t y = __shfl(cy, src, 64);
+        const uint64_t upw = __shfl_up(bw, 1, 64);
+        const uint32_t upy = __shfl_up(by, 1, 64);
+        if (cand_better(w, y, bw, by)) {
+            if (l > 0 && cand_better(w, y, upw, upy)) { bw = upw; by = upy; }
+            else { bw = w; by = y; }
+        }
+        tw = __shfl(bw, k - 1, 64);
+        tyy = __shfl(by, k - 1, 64);
+        m &= m - 1;
+        m &= __ballot(cw != 0 && cand_better(cw, cy, tw, tyy));
+    }
+}
+
+template <int LOG2T, int THREADS, int GROUP>
+__global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
+    constexpr int T = 1 << LOG2T;
+    constexpr int NW = THREADS / 64;
+    constexpr int NHW = THREADS / 32;
+    __shared__ uint32_t s_key[T];
+    __shared__ uint32_t s_v[3][T];
+    __shared__ uint64_t s_cw[MAX_KINDS][NW][MAX_K];
+    __shared__ uint32_t s_cy[MAX_KINDS][NW][MAX_K];
+    __shared__ uint32_t s_item;
+    __shared__ uint32_t s_ovf;
+
+    const int hw = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int wid = threadIdx.x >> 6;
+    const unsigned lane = lane_id();
+    uint32_t it = blockIdx.x;
+
+    for (;;) {
+        if (THREADS == S_THREADS) {
+            if (it >= a.n_items) break;
+        } else {
+            __syncthreads();
+            if (threadIdx.x == 0) s_item = atomicAdd(a.work_counter, 1u);
+            __syncthreads();
+            it = s_item;
+            if (it >= a.n_items) break;
+        }
+        const uint64_t item = a.items[it];
+        const uint32_t x = (uint32_t)(item & REC_AID_MASK);
+        const uint32_t part = (uint32_t)((item >> 26) & 0xFFFFFFu);
+        const int lgR = (int)(item >> 50);
+        const uint32_t pmask = (1u << lgR) - 1u;
+        const int pshift = 32 - LOG2T - lgR;
+
+        for (int i = threadIdx.x; i < T; i += THREADS) {
+            s_key[i] = KEY_EMPTY;
+            s_v[0][i] = 0; s_v[1][i] = 0; s_v[2][i] = 0;
+        }
+        if (threadIdx.x == 0) s_ovf = 0;
+        __syncthreads();
+
+        const uint64_t rb = a.run_start[x], re = a.run_start[x + 1];
+        for (uint64_t r = rb + hw; r < re; r += NHW) {
+            const uint64_t d = a.sorted_desc[r];
+            const uint32_t len = (uint32_t)(d & 0xFFull);
+            const uint64_t off = d >> 8;
+            if ((uint32_t)l < len) {
+                const uint32_t rc = a.rec[off + l];
+                const uint32_t y = rc & REC_AID_MASK;
+                const uint32_t h = y * 0x9E3779B1u;
+                bool take = lgR == 0 || ((h >> pshift) & pmask) == part;
+                uint32_t add0 = 0, add1 = 0, add2 = 0;
+                if (GROUP == OTTO_COVIS_GROUP_TYPE) {
+                    const uint32_t tyj = (rc >> REC_AID_BITS) & 3u;
+                    add0 = tyj == 0; add1 = tyj == 1; add2 = tyj == 2;
+                } else if (GROUP == OTTO_COVIS_GROUP_FILTER) {
+                    const uint32_t fb = (rc >> 28) >> a.chan_shift;
+                    add0 = fb & 1u; add1 = (fb >> 1) & 1u; add2 = (fb >> 2) & 1u;
+                    take = take && (add0 | add1 | add2);
+                }
+                if (take) {
+                    uint32_t slot = h >> (32 - LOG2T);
+                    int found = -1;
+                    for (int probe = 0; probe < T; ++probe) {
+                        const uint32_t kx = s_key[slot];
+                        if (kx == y) { found = (int)slot; break; }
+                        if (kx == KEY_EMPTY) {
+                            const uint32_t old = atomicCAS(&s_key[slot], KEY_EMPTY, y);
+                            if (old == KEY_EMPTY || old == y) { found = (int)slot; break; }
+                        }
+                        slot = (slot + 1) & (T - 1);
+                    }
+                    if (found < 0) {
+                        s_ovf = 1;
+                    } else if (GROUP == OTTO_COVIS_GROUP_TIME) {
+                        const uint32_t e = a.tw[off + l];
+                        atomicAdd(&s_v[0][found], 1u);
+                        const uint32_t old = atomicAdd(&s_v[1][found], e);
+                        if (old + e < old) atomicAdd(&s_v[2][found], 1u);
+                    } else {
+                        if (add0) atomicAdd(&s_v[0][found], 1u);
+                        if (add1) atomicAdd(&s_v[1][found], 1u);
+                        if (add2) atomicAdd(&s_v[2][found], 1u);
+                    }
+                }
+            }
+            if (lgR > 0 && s_ovf) break;
+        }
+        __syncthreads();
+        const bool ovf = s_ovf != 0;
+        if (ovf) {
+            // LDS table full: ask the host to redo this aid with twice the partitions
+            if (threadIdx.x == 0) {
+                a.flag[x] = 1;
+                a.boost[x] = (uint8_t)(lgR - l_log2r(a.cnt64[x] & CNT_REC_MASK, 0, a.l_cap) + 1);
+                atomicAdd(a.ovf_count, 1u);
+            }
+        } else {
+            // ---- per-wave top-k over a slice of the table, per kind ------------------------
+            for (int j = 0; j < a.nk; ++j) {
+                uint64_t bw = 0;
+                uint32_t by = 0;
+                for (int i = wid * 64 + (int)lane; i < T; i += NW * 64) {
+                    const uint32_t y = s_key[i];
+                    uint64_t w = 0;
+                    if (y != KEY_EMPTY) {
+                        if (GROUP == OTTO_COVIS_GROUP_TIME)
+                            w = 65536ull * s_v[0][i] + (((uint64_t)s_v[2][i] << 32) | s_v[1][i]);
+                        else
+                            w = 65536ull * ((uint64_t)s_v[0][i] * a.coef[j][0] + (uint64_t)s_v[1][i] * a.coef[j][1] +
+                                            (uint64_t)s_v[2][i] * a.coef[j][2]);
+                    }
+                    wave_topk_push(bw, by, w, y, a.k);
+                }
+                if ((int)lane < a.k) { s_cw[j][wid][lane] = bw; s_cy[j][wid][lane] = by; }
+            }
+            __syncthreads();
+            // ---- merge the NW partial lists: wave (j % NW) finishes kind j ------------------
+            for (int j = wid; j < a.nk; j += NW) {
+                uint64_t bw = 0;
+                uint32_t by = 0;
+                if (NW == 1) {
+                    bw = (int)lane < a.k ? s_cw[j][0][lane] : 0;
+                    by = (int)lane < a.k ? s_cy[j][0][lane] : 0;
+                } else {
+                    for (int c0 = 0; c0 < NW * a.k; c0 += 64) {
+                        const int c = c0 + (int)lane;
+                        uint64_t w = 0;
+                        uint32_t y = 0;
+                        if (c < NW * a.k) { w = s_cw[j][c / a.k][c % a.k]; y = s_cy[j][c / a.k][c % a.k]; }
+                        wave_topk_push(bw, by, w, y, a.k);
+                    }
+                }
+                const bool valid = (int)lane < a.k && bw != 0;
+                if (lgR == 0) {
+                    const size_t o = ((size_t)(a.kind_base + j) * a.n_aids + x) * (size_t)a.k + lane;
+                    if (valid) { a.out_y[o] = by; a.out_w[o] = bw; }
+                    const int nvalid = __popcll(__ballot(valid));
+                    if (lane == 0) a.out_n[(size_t)(a.kind_base + j) * a.n_aids + x] = nvalid;
+                } else if ((int)lane < a.k) {
+                    const size_t o = ((size_t)it * a.nk + j) * (size_t)a.k + lane;
+                    a.part_y[o] = by;
+                    a.part_w[o] = bw;
+                }
+            }
+        }
+        if (THREADS == S_THREADS) {
+            it += gridDim.x;
+            __syncthreads();
+        }
+    }
+}
+
+// merge the R partial top-k lists of one heavy aid (item with part == 0 and R > 1): one wave per item
+__global__ __launch_bounds__(64) void k_merge(ReduceArgs a) {
+    const uint32_t it = blockIdx.x;
+    if (it >= a.n_items) return;
+    const uint64_t item = a.items[it];
+    const uint32_t part = (uint32_t)((item >> 26) & 0xFFFFFFu);
+    const int lgR = (int)(item >> 50);
+    if (part != 0 || lgR == 0) return;
+    const uint32_t x = (uint32_t)(item & REC_AID_MASK);
+    if (a.flag[x]) return;
+    const unsigned lane = lane_id();
+    const uint64_t ncand = (uint64_t)a.k << lgR;
+    for (int j = 0; j < a.nk; ++j) {
+        uint64_t bw = 0;
+        uint32_t by = 0;
+        for (uint64_t c0 = 0; c0 < ncand; c0 += 64) {
+            const uint64_t c = c0 + lane;
+            uint64_t w = 0;
+            uint32_t y = 0;
+            if (c < ncand) {
+                const size_t o = ((size_t)(it + c / a.k) * a.nk + j) * (size_t)a.k + (c % a.k);
+                w = a.part_w[o];
+                y = a.part_y[o];
+            }
+            wave_topk_push(bw, by, w, y, a.k);
+        }
+        const bool valid = (int)lane < a.k && bw != 0;
+        const size_t o = ((size_t)(a.kind_base + j) * a.n_aids + x) * (size_t)a.k + lane;
+        if (valid) { a.out_y[o] = by; a.out_w[o] = bw; }
+        const int nvalid = __popcll(__ballot(valid));
+        if (lane == 0) a.out_n[(size_t)(a.kind_base + j) * a.n_aids + x] = nvalid;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// multi-GPU exchange helpers
+// ---------------------------------------------------------------------------
+struct ExportRuns {   // 1 if run slot i leaves for [lo, hi)
+    const uint32_t* run_x;
+    const uint64_t* run_desc;
+    uint32_t lo, hi;
+    __device__ uint64_t operator()(int64_t i) const {
+        const uint32_t x = run_x[i];
+        return ((run_desc[i] & 0xFFull) && x >= lo && x < hi) ? 1ull : 0ull;
+    }
+};
+struct ExportRecs {
+    const uint32_t* run_x;
+    const uint64_t* run_desc;
+    uint32_t lo, hi;
+    __device__ uint64_t operator()(int64_t i) const {
+        const uint32_t x = run_x[i];
+        const uint64_t len = run_desc[i] & 0xFFull;
+        return (len && x >= lo && x < hi) ? len : 0ull;
+    }
+};
+
+__global__ void k_export(const uint32_t* run_x, const uint64_t* run_desc, int64_t n_slots, uint32_t lo, uint32_t hi,
+                         const uint64_t* run_pos, const uint64_t* rec_pos, const uint32_t* rec, const uint32_t* tw,
+                         uint32_t* o_hdr, uint32_t* o_rec, uint32_t* o_tw) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t d = run_desc[i];
+        const uint32_t len = (uint32_t)(d & 0xFFull);
+        const uint32_t x = run_x[i];
+        if (len && x >= lo && x < hi) {
+            const uint64_t rp = run_pos[i], cp = rec_pos[i], off = d >> 8;
+            o_hdr[2 * rp] = x;
+            o_hdr[2 * rp + 1] = len;
+            for (uint32_t t = 0; t < len; ++t) {
+                o_rec[cp + t] = rec[off + t];
+                if (o_tw) o_tw[cp + t] = tw[off + t];
+            }
+        }
+    }
+}
+
+struct HdrLen {
+    const uint32_t* hdr;
+    __device__ uint64_t operator()(int64_t i) const { return hdr[2 * i + 1]; }
+};
+
+__global__ void k_import(const uint32_t* hdr, int64_t n_runs, const uint64_t* rec_pos, uint64_t rec_base,
+                         uint64_t run_base, uint32_t* run_x, uint64_t* run_desc) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += (int64_t)gridDim.x * blockDim.x) {
+        run_x[run_base + i] = hdr[2 * i];
+        run_desc[run_base + i] = ((rec_base + rec_pos[i]) << 8) | (uint64_t)hdr[2 * i + 1];
+    }
+}
+
+}  // namespace otto
+
+// ===========================================================================
+// host side
+// ===========================================================================
+using namespace otto;
+
+struct otto_covis_ctx {
+    otto_covis_params p;
+    // K1 products
+    DevBuf rec, tw, run_x, run_desc;
+    uint64_t rec_used = 0;    // record slots
+    uint64_t run_used = 0;    // run slots
+    int64_t sessions = 0;
+    // chunk scratch
+    DevBuf pair_base, ev_base, partial;
+    // index
+    bool index_valid = false;
+    DevBuf cnt64, run_start, cursor, sorted_desc, item_start, boost, flag, counters;
+    DevBuf items[3];
+    uint64_t n_items[3] = {0, 0, 0};
+    uint64_t n_pairs = 0, n_runs = 0;
+    // reduce scratch
+    DevBuf part_y, part_w;
+    DevBuf exp_run_pos, exp_rec_pos;
+    int64_t retries = 0;
+    uint32_t l_cap = L_CAP;
+    hipEvent_t ev[2 * OTTO_COVIS_T_COUNT];
+    bool ev_set[OTTO_COVIS_T_COUNT];
+    bool ev_ok = false;
+};
+
+static void tbegin(otto_covis_ctx* c, int i, hipStream_t s) {
+    if (c->ev_ok) { (void)hipEventRecord(c->ev[2 * i], s); }
+}
+static void tend(otto_covis_ctx* c, int i, hipStream_t s) {
+    if (c->ev_ok) { (void)hipEventRecord(c->ev[2 * i + 1], s); c->ev_set[i] = true; }
+}
+
+extern "C" const char* otto_last_error(void) { return g_err.c_str(); }
+
+extern "C" int otto_covis_create(otto_covis_ctx** out, const otto_covis_params* p) {
+    OTTO_REQUIRE(out && p, "otto_covis_create: null argument");
+    OTTO_REQUIRE(p->window >= 2 && p->window <= OTTO_COVIS_MAX_WINDOW, "window must be in [2, 32], got %d", p->window);
+    OTTO_REQUIRE(p->max_gap >= 0, "max_gap must be >= 0");
+    OTTO_REQUIRE(p->n_aids > 0 && p->n_aids <= OTTO_COVIS_MAX_AIDS, "n_aids must be in [1, 2^26], got %u", p->n_aids);
+    OTTO_REQUIRE(p->n_filters >= 0 && p->n_filters <= OTTO_COVIS_MAX_FILTERS, "n_filters must be in [0, 4]");
+    OTTO_REQUIRE(p->n_type_weights >= 0 && p->n_type_weights <= OTTO_COVIS_MAX_TYPE_WEIGHTS, "n_type_weights must be in [0, 4]");
+    OTTO_REQUIRE(p->ts_max >= p->ts_min, "ts_max < ts_min");
+    for (int j = 0; j < p->n_type_weights; ++j)
+        for (int t = 0; t < 3; ++t)
+            OTTO_REQUIRE(p->type_weight[j][t] > 0 && p->type_weight[j][t] < 65536, "type_weight[%d][%d] must be in [1, 65535]", j, t);
+    for (int f = 0; f < p->n_filters; ++f) OTTO_REQUIRE(p->filter_mask[f] < 512, "filter_mask[%d] has bits above 8", f);
+    otto_covis_ctx* c = new (std::nothrow) otto_covis_ctx();
+    OTTO_REQUIRE(c, "out of host memory");
+    c->p = *p;
+    c->ev_ok = true;
+    for (int i = 0; i < 2 * OTTO_COVIS_T_COUNT; ++i)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) c->ev_ok = false;
+    memset(c->ev_set, 0, sizeof c->ev_set);
+    *out = c;
+    return 0;
+}
+
+extern "C" void otto_covis_destroy(otto_covis_ctx* c) {
+    if (!c) return;
+    DevBuf* all[] = {&c->rec, &c->tw, &c->run_x, &c->run_desc, &c->pair_base, &c->ev_base, &c->partial, &c->cnt64,
+                     &c->run_start, &c->cursor, &c->sorted_desc, &c->item_start, &c->boost, &c->flag, &c->counters,
+                     &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->exp_run_pos, &c->exp_rec_pos};
+    for (DevBuf* b : all) b->release();
+    if (c->ev_ok)
+        for (int i = 0; i < 2 * OTTO_COVIS_T_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
+    delete c;
+}
+
+extern "C" int otto_covis_reset(otto_covis_ctx* c) {
+    OTTO_REQUIRE(c, "null ctx");
+    c->rec_used = c->run_used = 0;
+    c->sessions = 0;
+    c->index_valid = false;
+    c->n_pairs = c->n_runs = 0;
+    c->n_items[0] = c->n_items[1] = c->n_items[2] = 0;
+    memset(c->ev_set, 0, sizeof c->ev_set);
+    return 0;
+}
+
+extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const int32_t* d_ts, const uint8_t* d_type,
+                               const int64_t* d_sess_off, int64_t n_sess, void* stream) {
+    OTTO_REQUIRE(c && d_sess_off, "otto_covis_feed: null argument");
+    OTTO_REQUIRE(n_sess >= 0, "n_sess < 0");
+    if (n_sess == 0) return 0;
+    OTTO_REQUIRE(d_aid && d_ts && d_type, "otto_covis_feed: null event arrays");
+    hipStream_t s = (hipStream_t)stream;
+    const otto_covis_params& p = c->p;
+
+    tbegin(c, OTTO_COVIS_T_WINSCAN, s);
+    OTTO_TRY(c->pair_base.ensure((size_t)(n_sess + 1) * 8, 0, s));
+    OTTO_TRY(c->ev_base.ensure((size_t)(n_sess + 1) * 8, 0, s));
+    OTTO_TRY(c->partial.ensure(scan_partial_bytes(n_sess > (int64_t)p.n_aids ? n_sess : (int64_t)p.n_aids), 0, s));
+    OTTO_TRY(device_scan(WinPairs{d_sess_off, p.window}, n_sess, c->pair_base.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+    OTTO_TRY(device_scan(WinEvents{d_sess_off, p.window}, n_sess, c->ev_base.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+    tend(c, OTTO_COVIS_T_WINSCAN, s);
+    uint64_t totals[2];
+    OTTO_HIP(hipMemcpyAsync(&totals[0], c->pair_base.as<uint64_t>() + n_sess, 8, hipMemcpyDeviceToHost, s));
+    OTTO_HIP(hipMemcpyAsync(&totals[1], c->ev_base.as<uint64_t>() + n_sess, 8, hipMemcpyDeviceToHost, s));
+    OTTO_HIP(hipStreamSynchronize(s));
+    const uint64_t n_slots = totals[0], n_ev = totals[1];
+    OTTO_REQUIRE(c->rec_used + n_slots < (1ull << 55), "record slot space exhausted");
+
+    OTTO_TRY(c->rec.ensure((size_t)(c->rec_used + n_slots) * 4, (size_t)c->rec_used * 4, s));
+    if (p.want_time) OTTO_TRY(c->tw.ensure((size_t)(c->rec_used + n_slots) * 4, (size_t)c->rec_used * 4, s));
+    OTTO_TRY(c->run_x.ensure((size_t)(c->run_used + n_ev) * 4, (size_t)c->run_used * 4, s));
+    OTTO_TRY(c->run_desc.ensure((size_t)(c->run_used + n_ev) * 8, (size_t)c->run_used * 8, s));
+
+    ExpandArgs a;
+    a.aid = d_aid; a.ts = d_ts; a.type = d_type; a.sess_off = d_sess_off;
+    a.pair_base = c->pair_base.as<uint64_t>(); a.ev_base = c->ev_base.as<uint64_t>();
+    a.n_sess = n_sess;
+    a.rec = c->rec.as<uint32_t>(); a.tw = c->tw.as<uint32_t>();
+    a.run_x = c->run_x.as<uint32_t>(); a.run_desc = c->run_desc.as<uint64_t>();
+    a.rec_base = c->rec_used; a.run_base = c->run_used;
+    a.window = p.window; a.max_gap = p.max_gap;
+    a.t0 = p.ts_min; a.tspan = (int64_t)p.ts_max - (int64_t)p.ts_min;
+    for (int f = 0; f < 4; ++f) a.fmask[f] = f < p.n_filters ? p.filter_mask[f] : 0u;
+
+    int64_t groups = (n_sess + EXP_HW - 1) / EXP_HW;
+    int grid = (int)(groups < 256 * 16 ? groups : 256 * 16);
+    tbegin(c, OTTO_COVIS_T_EXPAND, s);
+    if (p.want_time) k_expand<true><<<grid, 256, 0, s>>>(a);
+    else k_expand<false><<<grid, 256, 0, s>>>(a);
+    OTTO_HIP(hipGetLastError());
+    tend(c, OTTO_COVIS_T_EXPAND, s);
+
+    c->rec_used += n_slots;
+    c->run_used += n_ev;
+    c->sessions += n_sess;
+    c->index_valid = false;
+    return 0;
+}
+
+static int build_items(otto_covis_ctx* c, int bin, int only_flagged, hipStream_t s) {
+    const uint32_t n_aids = c->p.n_aids;
+    ItemCount f{c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(), c->flag.as<uint32_t>(), bin, only_flagged, c->l_cap};
+    OTTO_TRY(device_scan(f, (int64_t)n_aids, c->item_start.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+    uint64_t total = 0;
+    OTTO_HIP(hipMemcpyAsync(&total, c->item_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
+    OTTO_HIP(hipStreamSynchronize(s));
+    OTTO_REQUIRE(total < (1ull << 32), "too many work items (%llu)", (unsigned long long)total);
+    c->n_items[bin] = total;
+    if (total) {
+        OTTO_TRY(c->items[bin].ensure((size_t)total * 8, 0, s));
+        k_fill_items<<<(n_aids + 255) / 256, 256, 0, s>>>(f, n_aids, c->item_start.as<uint64_t>(), c->items[bin].as<uint64_t>());
+        OTTO_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+static int build_index(otto_covis_ctx* c, hipStream_t s) {
+    const uint32_t n_aids = c->p.n_aids;
+    tbegin(c, OTTO_COVIS_T_INDEX, s);
+    OTTO_TRY(c->cnt64.ensure((size_t)n_aids * 8, 0, s));
+    OTTO_TRY(c->run_start.ensure((size_t)(n_aids + 1) * 8, 0, s));
+    OTTO_TRY(c->item_start.ensure((size_t)(n_aids + 1) * 8, 0, s));
+    OTTO_TRY(c->cursor.ensure((size_t)n_aids * 4, 0, s));
+    OTTO_TRY(c->boost.ensure((size_t)n_aids, 0, s));
+    OTTO_TRY(c->flag.ensure((size_t)n_aids * 4, 0, s));
+    OTTO_TRY(c->counters.ensure(64, 0, s));
+    OTTO_TRY(c->partial.ensure(scan_partial_bytes((int64_t)n_aids), 0, s));
+    OTTO_HIP(hipMemsetAsync(c->cnt64.p, 0, (size_t)n_aids * 8, s));
+    OTTO_HIP(hipMemsetAsync(c->cursor.p, 0, (size_t)n_aids * 4, s));
+    OTTO_HIP(hipMemsetAsync(c->boost.p, 0, (size_t)n_aids, s));
+    OTTO_HIP(hipMemsetAsync(c->flag.p, 0, (size_t)n_aids * 4, s));
+    const int64_t n_slots = (int64_t)c->run_used;
+    if (n_slots) {
+        int grid = (int)((n_slots + 255) / 256 < 256 * 32 ? (n_slots + 255) / 256 : 256 * 32);
+        k_hist_runs<<<grid, 256, 0, s>>>(c->run_x.as<uint32_t>(), c->run_desc.as<uint64_t>(), n_slots, c->cnt64.as<uint64_t>(), n_aids);
+        OTTO_HIP(hipGetLastError());
+    }
+    // total pairs (records) and runs
+    OTTO_TRY(device_scan(RecCount{c->cnt64.as<uint64_t>()}, (int64_t)n_aids, c->run_start.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+    uint64_t tot[2] = {0, 0};
+    OTTO_HIP(hipMemcpyAsync(&tot[0], c->run_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
+    OTTO_TRY(device_scan(RunCount{c->cnt64.as<uint64_t>()}, (int64_t)n_aids, c->run_start.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+    OTTO_HIP(hipMemcpyAsync(&tot[1], c->run_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
+    OTTO_HIP(hipStreamSynchronize(s));
+    c->n_pairs = tot[0];
+    c->n_runs = tot[1];
+    OTTO_TRY(c->sorted_desc.ensure((size_t)(c->n_runs ? c->n_runs : 1) * 8, 0, s));
+    if (n_slots) {
+        int grid = (int)((n_slots + 255) / 256 < 256 * 32 ? (n_slots + 255) / 256 : 256 * 32);
+        k_scatter_runs<<<grid, 256, 0, s>>>(c->run_x.as<uint32_t>(), c->run_desc.as<uint64_t>(), n_slots,
+                                            c->run_start.as<uint64_t>(), c->cursor.as<uint32_t>(),
+                                            c->sorted_desc.as<uint64_t>(), n_aids);
+        OTTO_HIP(hipGetLastError());
+    }
+    for (int bin = 0; bin < 3; ++bin) OTTO_TRY(build_items(c, bin, 0, s));
+    tend(c, OTTO_COVIS_T_INDEX, s);
+    c->retries = 0;
+    c->index_valid = true;
+    return 0;
+}
+
+template <int GROUP>
+static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s) {
+    a.items = c->items[bin].as<uint64_t>();
+    a.n_items = (uint32_t)c->n_items[bin];
+    if (a.n_items == 0) return 0;
+    uint32_t* wc = c->counters.as<uint32_t>() + 1 + bin;
+    OTTO_HIP(hipMemsetAsync(wc, 0, 4, s));
+    a.work_counter = wc;
+    if (bin == 0) {
+        uint32_t grid = a.n_items < 256u * 20u ? a.n_items : 256u * 20u;
+        tbegin(c, OTTO_COVIS_T_REDUCE_S, s);
+        k_reduce<S_LOG2T, S_THREADS, GROUP><<<grid, S_THREADS, 0, s>>>(a);
+        tend(c, OTTO_COVIS_T_REDUCE_S, s);
+    } else if (bin == 1) {
+        uint32_t grid = a.n_items < 256u * 2u ? a.n_items : 256u * 2u;
+        tbegin(c, OTTO_COVIS_T_REDUCE_M, s);
+        k_reduce<M_LOG2T, M_THREADS, GROUP><<<grid, M_THREADS, 0, s>>>(a);
+        tend(c, OTTO_COVIS_T_REDUCE_M, s);
+    } else {
+        uint32_t grid = a.n_items < 256u ? a.n_items : 256u;
+        tbegin(c, OTTO_COVIS_T_REDUCE_L, s);
+        k_reduce<L_LOG2T, L_THREADS, GROUP><<<grid, L_THREADS, 0, s>>>(a);
+        tend(c, OTTO_COVIS_T_REDUCE_L, s);
+        OTTO_HIP(hipGetLastError());
+        tbegin(c, OTTO_COVIS_T_MERGE, s);
+        k_merge<<<a.n_items, 64, 0, s>>>(a);
+        tend(c, OTTO_COVIS_T_MERGE, s);
+    }
+    OTTO_HIP(hipGetLastError());
+    return 0;
+}
+
+static int launch_reduce_group(otto_covis_ctx* c, const ReduceArgs& a, int bin, hipStream_t s) {
+    switch (a.group) {
+        case OTTO_COVIS_GROUP_TYPE: return launch_reduce<OTTO_COVIS_GROUP_TYPE>(c, a, bin, s);
+        case OTTO_COVIS_GROUP_FILTER: return launch_reduce<OTTO_COVIS_GROUP_FILTER>(c, a, bin, s);
+        default: return launch_reduce<OTTO_COVIS_GROUP_TIME>(c, a, bin, s);
+    }
+}
+
+extern "C" int otto_covis_finalize(otto_covis_ctx* c, int group, int k, uint32_t* d_out_y, uint64_t* d_out_w,
+                                   int32_t* d_out_n, void* stream) {
+    OTTO_REQUIRE(c && d_out_y && d_out_w && d_out_n, "otto_covis_finalize: null argument");
+    OTTO_REQUIRE(k >= 1 && k <= MAX_K, "k must be in [1, %d], got %d", MAX_K, k);
+    const otto_covis_params& p = c->p;
+    int n_kinds = 0;
+    switch (group) {
+        case OTTO_COVIS_GROUP_TYPE: n_kinds = p.n_type_weights; break;
+        case OTTO_COVIS_GROUP_FILTER: n_kinds = p.n_filters; break;
+        case OTTO_COVIS_GROUP_TIME:
+            OTTO_REQUIRE(p.want_time, "GROUP_TIME needs params.want_time");
+            n_kinds = 1;
+            break;
+        default: OTTO_REQUIRE(false, "unknown group %d", group);
+    }
+    OTTO_REQUIRE(n_kinds > 0, "group %d has no kinds configured", group);
+    hipStream_t s = (hipStream_t)stream;
+    if (!c->index_valid) OTTO_TRY(build_index(c, s));
+    const uint32_t n_aids = p.n_aids;
+    OTTO_HIP(hipMemsetAsync(d_out_n, 0, (size_t)n_kinds * n_aids * 4, s));
+
+    // FILTER passes carry 3 channels each; TYPE passes select up to 4 weight vectors from 3 counters.
+    const int per_pass = group == OTTO_COVIS_GROUP_FILTER ? 3 : MAX_KINDS;
+    for (int kb = 0; kb < n_kinds; kb += per_pass) {
+        ReduceArgs a;
+        memset(&a, 0, sizeof a);
+        a.cnt64 = c->cnt64.as<uint64_t>();
+        a.run_start = c->run_start.as<uint64_t>();
+        a.sorted_desc = c->sorted_desc.as<uint64_t>();
+        a.rec = c->rec.as<uint32_t>();
+        a.tw = c->tw.as<uint32_t>();
+        a.group = group;
+        a.nk = n_kinds - kb < per_pass ? n_kinds - kb : per_pass;
+        a.k = k;
+        a.chan_shift = group == OTTO_COVIS_GROUP_FILTER ? kb : 0;
+        for (int j = 0; j < a.nk; ++j)
+            for (int t = 0; t < 3; ++t)
+                a.coef[j][t] = group == OTTO_COVIS_GROUP_TYPE ? (uint32_t)p.type_weight[kb + j][t] : (uint32_t)(t == j);
+        a.n_aids = n_aids;
+        a.kind_base = kb;
+        a.out_y = d_out_y; a.out_w = d_out_w; a.out_n = d_out_n;
+        a.flag = c->flag.as<uint32_t>();
+        a.boost = c->boost.as<uint8_t>();
+        a.ovf_count = c->counters.as<uint32_t>();
+        a.l_cap = c->l_cap;
+
+        bool first = true;
+        for (;;) {
+            OTTO_HIP(hipMemsetAsync(c->counters.p, 0, 4, s));
+            if (c->n_items[2]) {
+                const size_t need = (size_t)c->n_items[2] * a.nk * k;
+                OTTO_TRY(c->part_y.ensure(need * 4, 0, s));
+                OTTO_TRY(c->part_w.ensure(need * 8, 0, s));
+                a.part_y = c->part_y.as<uint32_t>();
+                a.part_w = c->part_w.as<uint64_t>();
+            }
+            if (first) {
+                OTTO_TRY(launch_reduce_group(c, a, 0, s));
+                OTTO_TRY(launch_reduce_group(c, a, 1, s));
+            }
+            OTTO_TRY(launch_reduce_group(c, a, 2, s));
+            uint32_t ovf = 0;
+            OTTO_HIP(hipMemcpyAsync(&ovf, c->counters.p, 4, hipMemcpyDeviceToHost, s));
+            OTTO_HIP(hipStreamSynchronize(s));
+            if (ovf == 0) break;
+            // some heavy aids overflowed their LDS table: re-partition only those (boost[x] was raised)
+            c->retries++;
+            OTTO_REQUIRE(c->retries < 64, "overflow re-partitioning did not converge");
+            OTTO_TRY(build_items(c, 2, 1, s));
+            OTTO_HIP(hipMemsetAsync(c->flag.p, 0, (size_t)n_aids * 4, s));
+            first = false;
+        }
+        if (!first) OTTO_TRY(build_items(c, 2, 0, s));   // restore the full L list (boost kept) for later passes
+    }
+    return 0;
+}
+
+extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_t value) {
+    OTTO_REQUIRE(c && name, "null argument");
+    if (strcmp(name, "l_cap") == 0) {
+        // records per hash partition of a heavy aid (L bin). Larger = fewer passes over the aid's
+        // records but more LDS-table overflows (each costs a re-partition round); any value is exact.
+        OTTO_REQUIRE(value >= 64 && value <= (1ll << 30), "l_cap out of range");
+        c->l_cap = (uint32_t)value;
+        c->index_valid = false;
+        return 0;
+    }
+    OTTO_REQUIRE(false, "unknown option '%s'", name);
+}
+
+extern "C" int otto_covis_stats(otto_covis_ctx* c, int64_t* out) {
+    OTTO_REQUIRE(c && out, "null argument");
+    out[OTTO_COVIS_STAT_SESSIONS] = c->sessions;
+    out[OTTO_COVIS_STAT_TAIL_EVENTS] = (int64_t)c->run_used;
+    out[OTTO_COVIS_STAT_PAIR_SLOTS] = (int64_t)c->rec_used;
+    out[OTTO_COVIS_STAT_PAIRS] = (int64_t)c->n_pairs;
+    out[OTTO_COVIS_STAT_RUNS] = (int64_t)c->n_runs;
+    out[OTTO_COVIS_STAT_ITEMS_S] = (int64_t)c->n_items[0];
+    out[OTTO_COVIS_STAT_ITEMS_M] = (int64_t)c->n_items[1];
+    out[OTTO_COVIS_STAT_ITEMS_L] = (int64_t)c->n_items[2];
+    out[OTTO_COVIS_STAT_RETRIES] = c->retries;
+    return 0;
+}
+
+extern "C" int otto_covis_timings(otto_covis_ctx* c, float* out_ms) {
+    OTTO_REQUIRE(c && out_ms, "null argument");
+    for (int i = 0; i < OTTO_COVIS_T_COUNT; ++i) {
+        out_ms[i] = 0.f;
+        if (c->ev_ok && c->ev_set[i]) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]) == hipSuccess) out_ms[i] = ms;
+        }
+    }
+    return OTTO_COVIS_T_COUNT;
+}
+
+extern "C" int otto_covis_copy_records(otto_covis_ctx* c, uint32_t* h_rec, uint32_t* h_tw, uint32_t* h_run_x,
+                                       uint64_t* h_run_desc) {
+    OTTO_REQUIRE(c, "null ctx");
+    OTTO_HIP(hipDeviceSynchronize());
+    if (h_rec && c->rec_used) OTTO_HIP(hipMemcpy(h_rec, c->rec.p, (size_t)c->rec_used * 4, hipMemcpyDeviceToHost));
+    if (h_tw && c->rec_used) {
+        OTTO_REQUIRE(c->p.want_time, "no time channel (want_time == 0)");
+        OTTO_HIP(hipMemcpy(h_tw, c->tw.p, (size_t)c->rec_used * 4, hipMemcpyDeviceToHost));
+    }
+    if (h_run_x && c->run_used) OTTO_HIP(hipMemcpy(h_run_x, c->run_x.p, (size_t)c->run_used * 4, hipMemcpyDeviceToHost));
+    if (h_run_desc && c->run_used) OTTO_HIP(hipMemcpy(h_run_desc, c->run_desc.p, (size_t)c->run_used * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int otto_covis_export_count(otto_covis_ctx* c, uint32_t x_lo, uint32_t x_hi, int64_t* n_runs, int64_t* n_recs,
+                                       void* stream) {
+    OTTO_REQUIRE(c && n_runs && n_recs, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n_slots = (int64_t)c->run_used;
+    OTTO_TRY(c->exp_run_pos.ensure((size_t)(n_slots + 1) * 8, 0, s));
+    OTTO_TRY(c->exp_rec_pos.ensure((size_t)(n_slots + 1) * 8, 0, s));
+    OTTO_TRY(c->partial.ensure(scan_partial_bytes(n_slots), 0, s));
+    OTTO_TRY(device_scan(ExportRuns{c->run_x.as<uint32_t>(), c->run_desc.as<uint64_t>(), x_lo, x_hi}, n_slots,
+                         c->exp_run_pos.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+    OTTO_TRY(device_scan(ExportRecs{c->run_x.as<uint32_t>(), c->run_desc.as<uint64_t>(), x_lo, x_hi}, n_slots,
+                         c->exp_rec_pos.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+    uint64_t t[2];
+    OTTO_HIP(hipMemcpyAsync(&t[0], c->exp_run_pos.as<uint64_t>() + n_slots, 8, hipMemcpyDeviceToHost, s));
+    OTTO_HIP(hipMemcpyAsync(&t[1], c->exp_rec_pos.as<uint64_t>() + n_slots, 8, hipMemcpyDeviceToHost, s));
+    OTTO_HIP(hipStreamSynchronize(s));
+    *n_runs = (int64_t)t[0];
+    *n_recs = (int64_t)t[1];
+    return 0;
+}
+
+extern "C" int otto_covis_export_runs(otto_covis_ctx* c, uint32_t x_lo, uint32_t x_hi, uint32_t* d_hdr, uint32_t* d_rec,
+                                      uint32_t* d_tw, void* stream) {
+    OTTO_REQUIRE(c, "null ctx");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t nr = 0, nc = 0;
+    OTTO_TRY(otto_covis_export_count(c, x_lo, x_hi, &nr, &nc, stream));
+    if (nr == 0) return 0;
+    OTTO_REQUIRE(d_hdr && d_rec, "null export buffers");
+    OTTO_REQUIRE(!d_tw || c->p.want_time, "no time channel to export");
+    const int64_t n_slots = (int64_t)c->run_used;
+    int grid = (int)((n_slots + 255) / 256 < 256 * 32 ? (n_slots + 255) / 256 : 256 * 32);
+    k_export<<<grid, 256, 0, s>>>(c->run_x.as<uint32_t>(), c->run_desc.as<uint64_t>(), n_slots, x_lo, x_hi,
+                                  c->exp_run_pos.as<uint64_t>(), c->exp_rec_pos.as<uint64_t>(), c->rec.as<uint32_t>(),
+                                  c->tw.as<uint32_t>(), d_hdr, d_rec, d_tw);
+    OTTO_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int otto_covis_import_runs(otto_covis_ctx* c, const uint32_t* d_hdr, int64_t n_runs, const uint32_t* d_rec,
+                                      const uint32_t* d_tw, int64_t n_recs, void* stream) {
+    OTTO_REQUIRE(c, "null ctx");
+    if (n_runs == 0) return 0;
+    OTTO_REQUIRE(d_hdr && d_rec && n_runs > 0 && n_recs > 0, "bad import buffers");
+    OTTO_REQUIRE(!c->p.want_time || d_tw, "context keeps the time channel: d_tw required");
+    hipStream_t s = (hipStream_t)stream;
+    OTTO_TRY(c->exp_rec_pos.ensure((size_t)(n_runs + 1) * 8, 0, s));
+    OTTO_TRY(c->partial.ensure(scan_partial_bytes(n_runs), 0, s));
+    OTTO_TRY(device_scan(HdrLen{d_hdr}, n_runs, c->exp_rec_pos.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+    OTTO_TRY(c->rec.ensure((size_t)(c->rec_used + n_recs) * 4, (size_t)c->rec_used * 4, s));
+    if (c->p.want_time) OTTO_TRY(c->tw.ensure((size_t)(c->rec_used + n_recs) * 4, (size_t)c->rec_used * 4, s));
+    OTTO_TRY(c->run_x.ensure((size_t)(c->run_used + n_runs) * 4, (size_t)c->run_used * 4, s));
+    OTTO_TRY(c->run_desc.ensure((size_t)(c->run_used + n_runs) * 8, (size_t)c->run_used * 8, s));
+    OTTO_HIP(hipMemcpyAsync(c->rec.as<uint32_t>() + c->rec_used, d_rec, (size_t)n_recs * 4, hipMemcpyDeviceToDevice, s));
+    if (c->p.want_time)
+        OTTO_HIP(hipMemcpyAsync(c->tw.as<uint32_t>() + c->rec_used, d_tw, (size_t)n_recs * 4, hipMemcpyDeviceToDevice, s));
+    int grid = (int)((n_runs + 255) / 256 < 256 * 32 ? (n_runs + 255) / 256 : 256 * 32);
+    k_import<<<grid, 256, 0, s>>>(d_hdr, n_runs, c->exp_rec_pos.as<uint64_t>(), c->rec_used, c->run_used,
+                                  c->run_x.as<uint32_t>(), c->run_desc.as<uint64_t>());
+    OTTO_HIP(hipGetLastError());
+    c->rec_used += (uint64_t)n_recs;
+    c->run_used += (uint64_t)n_runs;
+    c->index_valid = false;
+    return 0;
+}
