@@ -1,0 +1,231 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the hot path (BASELINE.json metric).
+
+`python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.
+
+A "step" is one full covisitation build over one batch of synthetic OTTO-shape
+sessions that are already resident in HBM: pair-expand -> inverted index ->
+LDS hash reduce -> top-20 per aid for the 3 type-weighted matrices
+(BASELINE.json configs[1]).  value = deduped ordered aid-pairs expanded and
+reduced per second, whole job (sum over ranks).  N > 1: every rank holds its own
+`--sessions` sessions (weak scaling) and the expanded runs are exchanged by
+aid_x owner over RCCL before the reduce (covisitation/distributed.py).
+
+The JSON line also carries
+  roofline     : the dominant kernel (by device time) against the HBM peak, from
+                 HIP events recorded on the kernel's own stream inside the library
+  roofline_expand : same for the pair-expand kernel (the kernel the north star's
+                 40 % target names)
+  cpu_baseline : the CPU oracle timed on a bounded sample of the same stream
+  mf           : BPR-MF training throughput (second half of the metric), when built
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BENCH_KINDS = ('click_weighted', 'cart_weighted', 'order_weighted')
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--sessions', type=int, default=14_571_582, help='sessions per rank (full OTTO = 14,571,582)')
+    ap.add_argument('--k', type=int, default=20)
+    ap.add_argument('--cpu-sessions', type=int, default=150_000, help='sample size of the cpu_baseline leg (0 = skip)')
+    ap.add_argument('--no-mf', action='store_true')
+    ap.add_argument('--mf-rows', type=int, default=200_000_000)
+    ap.add_argument('--mf-factors', type=int, default=64)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(st, k, nk):
+    """Algorithmic HBM bytes per launch of each kernel (DESIGN.md 'Measurement')."""
+    S, Et, P = st['sessions'], st['tail_events'], st['pairs']
+    out = {
+        # read aid 4 + ts 4 + type 1 per window event, 3 x 8 B per session (CSR offset + two slot bases);
+        # write one 4-byte record per pair and one (aid_x u32, descriptor u64) per window event
+        'expand': 9 * Et + 24 * S + 4 * P + 12 * Et,
+    }
+    for b, name in (('s', 'reduce_s'), ('m', 'reduce_m'), ('l', 'reduce_l')):
+        aids = st[f'items_{b}'] if b != 'l' else 0
+        # read every record (4 B) and run descriptor (8 B) of the bin once, 24 B of item/run_start
+        # lookups per item, write nk top-k lists per aid (k x 12 B + 4 B)
+        out[name] = 4 * st[f'pairs_{b}'] + 8 * st[f'runs_{b}'] + 24 * st[f'items_{b}'] + aids * nk * (12 * k + 4)
+    return out
+
+
+def roofline_obj(name, ms, nbytes):
+    gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {'kernel': name, 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'avg_ms': round(ms, 4), 'algorithmic_bytes': int(nbytes)}
+
+
+def cpu_baseline(dev_data, n_sessions, k):
+    """Time the CPU restatement (oracle/, kind 'port') on the first n_sessions of the same stream."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import numpy as np
+    off = dev_data['sess_off'][:n_sessions + 1].cpu().numpy()
+    e = int(off[-1])
+    aid = dev_data['aid'][:e].cpu().numpy().astype(np.uint32)
+    ts = dev_data['ts'][:e].cpu().numpy()
+    typ = dev_data['type'][:e].cpu().numpy()
+    try:
+        import covis_oracle_c as coc
+    except Exception:
+        coc = None
+    if coc is not None and coc.available():
+        cores = os.cpu_count() or 1
+        t0 = time.time()
+        pairs = coc.covis_topk_c(aid, ts, typ, off, dev_data['n_aids'], BENCH_KINDS, k=k, threads=cores)['P']
+        dt = time.time() - t0
+        impl = f'oracle/covis_oracle.c (OpenMP, {cores} threads)'
+    else:
+        import covis_oracle as co
+        cores = 1
+        st = {}
+        t0 = time.time()
+        co.covis_topk_numpy(aid, ts, typ, off, co.CovisSpec(kinds=BENCH_KINDS), k=k, stats=st)
+        dt = time.time() - t0
+        pairs = st['P']
+        impl = 'oracle/covis_oracle.py (NumPy)'
+    return {'value': round(pairs / dt, 1), 'unit': 'aid-pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': f'first {n_sessions} sessions of the same synthetic stream ({e} events, {pairs} pairs), '
+                      f'{impl}, {dt:.1f} s wall', 'host_cores_available': os.cpu_count()}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from otto_amd.synth import generate_sessions_torch, OTTO_N_AIDS
+    from otto_amd.covisitation.engine import CovisBuilder
+    from otto_amd.covisitation.distributed import ShardedCovisBuilder, global_ts_range
+    from otto_amd import _lib
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}')
+    dev = torch.device(f'cuda:{local_rank}')
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    data = generate_sessions_torch(a.sessions, n_aids=OTTO_N_AIDS, seed=42 + rank, device=dev)
+    n_aids = data['n_aids']
+    if world > 1:
+        ts_min, ts_max = global_ts_range(data['ts'])
+        builder = ShardedCovisBuilder(n_aids, BENCH_KINDS, ts_min, ts_max, dev)
+        eng = builder.owner
+    else:
+        ts_min, ts_max = int(data['ts'].min()), int(data['ts'].max())
+        builder = CovisBuilder(n_aids, kinds=BENCH_KINDS, ts_min=ts_min, ts_max=ts_max, device=dev)
+        eng = builder
+    nk = len(BENCH_KINDS)
+    out = {_lib.GROUP_TYPE: (torch.empty((nk, n_aids, a.k), dtype=torch.int32, device=dev),
+                             torch.empty((nk, n_aids, a.k), dtype=torch.int64, device=dev),
+                             torch.empty((nk, n_aids), dtype=torch.int32, device=dev))}
+
+    def step():
+        builder.reset()
+        builder.feed(data['aid'], data['ts'], data['type'], data['sess_off'])
+        builder.finalize(k=a.k, out=out)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    kernel_ms = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        for src in ((builder.local, eng) if world > 1 else (eng,)):   # finalize() has already synchronised
+            for name, ms in src.timings().items():
+                kernel_ms[name] = kernel_ms.get(name, 0.0) + ms
+    barrier()
+    dt = time.perf_counter() - t0
+    st = eng.stats()
+    st_expand = builder.local.stats() if world > 1 else st
+    pairs = st['pairs']
+    if world > 1:
+        red = torch.tensor([dt, float(pairs)], dtype=torch.float64, device=dev)
+        mx = red.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = red.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt, pairs = float(mx[0].item()), int(sm[1].item())
+
+    result = None
+    if rank == 0:
+        kernel_ms = {k_: v / a.steps for k_, v in kernel_ms.items()}
+        if world > 1:   # the expand kernel ran on the local engine; its P = records this rank exported
+            st_k = {**st, 'sessions': st_expand['sessions'], 'tail_events': st_expand['tail_events'],
+                    'pairs': builder.last_exchange[1]}
+        else:
+            st_k = st
+        ab = algorithmic_bytes(st_k, a.k, nk)
+        cand = {n: kernel_ms.get(n, 0.0) for n in ('expand', 'reduce_s', 'reduce_m', 'reduce_l')}
+        dom = max(cand, key=cand.get)
+        knames = {'expand': 'k_expand<false>', 'reduce_s': 'k_reduce<9,64,TYPE>', 'reduce_m': 'k_reduce<12,256,TYPE>',
+                  'reduce_l': 'k_reduce<13,1024,TYPE>'}
+        result = {
+            'metric': 'aid-pairs/sec covisitation build',
+            'value': round(pairs * a.steps / dt, 1),
+            'unit': 'aid-pairs/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(1e3 * dt / a.steps, 3),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'u64',
+            'data': 'synthetic',
+            'config': {
+                'workload': f'full-OTTO-shape covisitation: {a.sessions} synthetic sessions per GPU, '
+                            f'{data["aid"].numel()} events, {n_aids} aids, window=30, max_gap=86400 s, '
+                            f'3 type-weighted matrices (click/cart/order_weighted), top-{a.k}/aid',
+                'sessions_per_gpu': a.sessions, 'events_per_gpu': int(data['aid'].numel()),
+                'pairs_total': int(pairs), 'kinds': list(BENCH_KINDS), 'k': a.k,
+                'parallelism': 'single GPU' if world == 1 else f'session-chunk x{world}, RCCL all-to-all-v of expanded runs by aid_x owner',
+            },
+            'roofline': roofline_obj(knames[dom], cand[dom], ab[dom]),
+            'roofline_expand': roofline_obj(knames['expand'], cand['expand'], ab['expand']),
+            'kernel_ms': {k_: round(v, 3) for k_, v in kernel_ms.items()},
+            'stats': st,
+        }
+    # ---- second half of the metric: BPR-MF triplets/s ----------------------------------------------
+    if not a.no_mf:
+        try:
+            from otto_amd.matrix_factorization import bench_mf
+        except ModuleNotFoundError:
+            bench_mf = None
+        if bench_mf is not None:
+            del builder, eng, out
+            torch.cuda.empty_cache()
+            mf = bench_mf.run(a, dev, rank, world)
+            if rank == 0:
+                result['mf'] = mf
+    if rank == 0 and world == 1 and a.cpu_sessions > 0:
+        result['cpu_baseline'] = cpu_baseline(data, min(a.cpu_sessions, a.sessions), a.k)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

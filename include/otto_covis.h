@@ -70,6 +70,12 @@ enum {
     OTTO_COVIS_STAT_ITEMS_M,
     OTTO_COVIS_STAT_ITEMS_L,
     OTTO_COVIS_STAT_RETRIES,        /* overflow re-partition rounds since the index was built */
+    OTTO_COVIS_STAT_PAIRS_S,        /* expanded pairs reduced by the S / M / L size bins  */
+    OTTO_COVIS_STAT_PAIRS_M,
+    OTTO_COVIS_STAT_PAIRS_L,
+    OTTO_COVIS_STAT_RUNS_S,         /* runs gathered by the S / M / L size bins            */
+    OTTO_COVIS_STAT_RUNS_M,
+    OTTO_COVIS_STAT_RUNS_L,
     OTTO_COVIS_STAT_COUNT
 };
 

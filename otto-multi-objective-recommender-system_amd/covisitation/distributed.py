@@ -1,0 +1,89 @@
+"""Multi-GPU covisitation build: one process per GPU, sessions sharded by contiguous
+session-chunk, ONE exchange step over RCCL/xGMI (SURVEY.md section 8 e).
+
+Merging per-GPU top-k lists would be inexact (a pair's weight is a sum over
+shards), so what is exchanged is the expanded pairs themselves: every rank runs
+the pair-expand kernel on its session chunk, the (window, aid_x) runs are routed
+to the owner of ``aid_x`` (disjoint aid ranges -- the reference's disk-part idea,
+``src/covisitation/inference.py:87-89``) with a single all-to-all-v, and each owner
+reduces and selects its aid range locally.  The result is bit-identical to the
+single-GPU build.  xGMI is point-to-point, so an all-to-all (every link busy at
+once) rather than a ring collective is the right shape; records are 4 bytes/pair.
+"""
+import numpy as np
+
+
+def owner_bounds(n_aids, world):
+    """world+1 cut points of the aid_x owner ranges."""
+    return [int(round(i * n_aids / world)) for i in range(world + 1)]
+
+
+def exchange_runs(export_fn, import_fn, bounds, group=None, want_time=False):
+    """Route runs to their aid_x owners.
+
+    ``export_fn(lo, hi) -> (hdr int32 [n,2], rec int32 [m], tw int32 [m] | None)`` on the local
+    engine, ``import_fn(hdr, rec, tw)`` on the owner engine.  Works on any tensor device the
+    process group supports (nccl: device tensors; gloo: CPU tensors in the tests).
+    Returns (runs_sent, recs_sent, runs_received, recs_received).
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    pieces = [export_fn(bounds[r], bounds[r + 1]) for r in range(world)]
+    dev = pieces[0][0].device
+    send_counts = torch.tensor([[p[0].shape[0], p[1].numel()] for p in pieces], dtype=torch.int64, device=dev)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    sc = send_counts.cpu().numpy()
+    rc = recv_counts.cpu().numpy()
+
+    def a2a(chunks, per_item, s_cnt, r_cnt):
+        send = torch.cat([c.reshape(-1) for c in chunks]) if chunks else torch.empty(0, dtype=torch.int32, device=dev)
+        recv = torch.empty(int(r_cnt.sum()) * per_item, dtype=torch.int32, device=dev)
+        dist.all_to_all_single(recv, send, [int(v) * per_item for v in r_cnt], [int(v) * per_item for v in s_cnt], group=group)
+        return recv
+
+    hdr = a2a([p[0] for p in pieces], 2, sc[:, 0], rc[:, 0]).reshape(-1, 2)
+    rec = a2a([p[1] for p in pieces], 1, sc[:, 1], rc[:, 1])
+    tw = a2a([p[2] for p in pieces], 1, sc[:, 1], rc[:, 1]) if want_time else None
+    import_fn(hdr, rec, tw)
+    return int(sc[:, 0].sum()), int(sc[:, 1].sum()), int(rc[:, 0].sum()), int(rc[:, 1].sum())
+
+
+def global_ts_range(ts, group=None):
+    """t0 / t1 of the time weight must be global over all ranks (SPEC-COVIS 6)."""
+    import torch
+    import torch.distributed as dist
+    lo = ts.min().to(torch.int64).reshape(1) if ts.numel() else torch.full((1,), 2 ** 62, dtype=torch.int64, device=ts.device)
+    hi = ts.max().to(torch.int64).reshape(1) if ts.numel() else torch.full((1,), -2 ** 62, dtype=torch.int64, device=ts.device)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return int(lo.item()), int(hi.item())
+
+
+class ShardedCovisBuilder:
+    """Session-chunk sharded build on ``world`` GPUs; rank r owns aid_x in
+    ``[bounds[r], bounds[r+1])`` and returns top-k rows for that range only."""
+
+    def __init__(self, n_aids, kinds, ts_min, ts_max, device, group=None, window=30, max_gap=86400):
+        import torch.distributed as dist
+        from .engine import CovisBuilder
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.bounds = owner_bounds(n_aids, self.world)
+        kw = dict(kinds=kinds, window=window, max_gap=max_gap, ts_min=ts_min, ts_max=ts_max, device=device)
+        self.local = CovisBuilder(n_aids, **kw)    # expands this rank's session chunk
+        self.owner = CovisBuilder(n_aids, **kw)    # holds the runs of this rank's aid range
+
+    def reset(self):
+        self.local.reset()
+        self.owner.reset()
+
+    def feed(self, aid, ts, typ, sess_off):
+        self.local.feed(aid, ts, typ, sess_off)
+
+    def finalize(self, k=20, out=None):
+        self.last_exchange = exchange_runs(self.local.export_runs, self.owner.import_runs, self.bounds, self.group,
+                                           self.local.want_time)
+        return self.owner.finalize(k=k, out=out)

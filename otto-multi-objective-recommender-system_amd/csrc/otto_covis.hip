@@ -316,6 +316,26 @@ struct ItemCount {   // number of work items aid x contributes to bin `bin`
     }
 };
 
+struct BinRecs {     // expanded pairs of aid x if it falls in bin `bin`
+    const uint64_t* cnt64;
+    int bin;
+    __device__ uint64_t operator()(int64_t x) const {
+        const uint64_t n = cnt64[x] & CNT_REC_MASK;
+        const int b = n <= (uint64_t)S_CAP ? 0 : (n <= (uint64_t)M_CAP ? 1 : 2);
+        return b == bin ? n : 0;
+    }
+};
+
+struct BinRuns {     // runs of aid x if it falls in bin `bin`
+    const uint64_t* cnt64;
+    int bin;
+    __device__ uint64_t operator()(int64_t x) const {
+        const uint64_t n = cnt64[x] & CNT_REC_MASK;
+        const int b = n <= (uint64_t)S_CAP ? 0 : (n <= (uint64_t)M_CAP ? 1 : 2);
+        return b == bin ? (cnt64[x] >> 40) : 0;
+    }
+};
+
 // item = x | part << 26 | log2R << 50
 __global__ void k_fill_items(ItemCount f, uint32_t n_aids, const uint64_t* item_start, uint64_t* items) {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -652,6 +672,8 @@ struct otto_covis_ctx {
     DevBuf cnt64, run_start, cursor, sorted_desc, item_start, boost, flag, counters;
     DevBuf items[3];
     uint64_t n_items[3] = {0, 0, 0};
+    uint64_t bin_pairs[3] = {0, 0, 0};
+    uint64_t bin_runs[3] = {0, 0, 0};
     uint64_t n_pairs = 0, n_runs = 0;
     // reduce scratch
     DevBuf part_y, part_w;
@@ -826,7 +848,15 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
                                             c->sorted_desc.as<uint64_t>(), n_aids);
         OTTO_HIP(hipGetLastError());
     }
-    for (int bin = 0; bin < 3; ++bin) OTTO_TRY(build_items(c, bin, 0, s));
+    for (int bin = 0; bin < 3; ++bin) {
+        OTTO_TRY(device_scan(BinRecs{c->cnt64.as<uint64_t>(), bin}, (int64_t)n_aids, c->item_start.as<uint64_t>(),
+                             c->partial.as<uint64_t>(), s));
+        OTTO_HIP(hipMemcpyAsync(&c->bin_pairs[bin], c->item_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
+        OTTO_TRY(device_scan(BinRuns{c->cnt64.as<uint64_t>(), bin}, (int64_t)n_aids, c->item_start.as<uint64_t>(),
+                             c->partial.as<uint64_t>(), s));
+        OTTO_HIP(hipMemcpyAsync(&c->bin_runs[bin], c->item_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
+        OTTO_TRY(build_items(c, bin, 0, s));
+    }
     tend(c, OTTO_COVIS_T_INDEX, s);
     c->retries = 0;
     c->index_valid = true;
@@ -974,6 +1004,12 @@ extern "C" int otto_covis_stats(otto_covis_ctx* c, int64_t* out) {
     out[OTTO_COVIS_STAT_ITEMS_M] = (int64_t)c->n_items[1];
     out[OTTO_COVIS_STAT_ITEMS_L] = (int64_t)c->n_items[2];
     out[OTTO_COVIS_STAT_RETRIES] = c->retries;
+    out[OTTO_COVIS_STAT_PAIRS_S] = (int64_t)c->bin_pairs[0];
+    out[OTTO_COVIS_STAT_PAIRS_M] = (int64_t)c->bin_pairs[1];
+    out[OTTO_COVIS_STAT_PAIRS_L] = (int64_t)c->bin_pairs[2];
+    out[OTTO_COVIS_STAT_RUNS_S] = (int64_t)c->bin_runs[0];
+    out[OTTO_COVIS_STAT_RUNS_M] = (int64_t)c->bin_runs[1];
+    out[OTTO_COVIS_STAT_RUNS_L] = (int64_t)c->bin_runs[2];
     return 0;
 }
 

@@ -187,3 +187,21 @@ def test_deterministic_across_runs(gpu_device):
     _, a = _build(ev, gpu_device)
     _, b = _build(ev, gpu_device)
     _assert_rows_equal(a, b, cs.ALL_KINDS)
+
+
+def test_golden_fixture_and_hand_computed_sessions(gpu_device):
+    """The committed golden rows (tests/golden/covis_golden.npz) and the hand-derived micro-sessions
+    of tests/test_covis_oracle.py, through the HIP path."""
+    import os
+    from conftest import GOLDEN
+    from test_covis_oracle import _micro, HAND, HAND_TIME
+    g = np.load(os.path.join(GOLDEN, 'covis_golden.npz'))
+    ev = Events(aid=g['aid'], ts=g['ts'], type=g['type'], sess_off=g['sess_off'], n_aids=int(g['n_aids']))
+    _, got = _build(ev, gpu_device)
+    _assert_rows_equal(got, {k: (g[f'{k}_x'], g[f'{k}_y'], g[f'{k}_w']) for k in cs.ALL_KINDS}, cs.ALL_KINDS)
+    aid, ts, typ, off = _micro()
+    _, got = _build(Events(aid=aid, ts=ts, type=typ, sess_off=off, n_aids=31), gpu_device)
+    for kind, want in list(HAND.items()) + [('time_weighted', None)]:
+        gx, gy, gw = got[kind]
+        d = dict(zip(zip(gx.tolist(), gy.tolist()), gw.tolist()))
+        assert d == ({p: w * cs.Q16 for p, w in want.items()} if want is not None else HAND_TIME), kind

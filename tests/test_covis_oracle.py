@@ -1,0 +1,100 @@
+"""CPU tests of the covisitation oracle: hand-computed micro-sessions, the two
+restatements against each other, the committed golden fixture, top-k tie-breaking."""
+import os
+
+import numpy as np
+import pytest
+
+import covis_oracle as co
+from conftest import GOLDEN
+from otto_amd.synth import generate_sessions
+
+T = 1_660_000_000
+Q = co.Q16
+
+
+def _micro():
+    # session 1: aids 10,20,10,30 (click, click, cart, order); session 2: one pair more than a day
+    # apart (no contribution); session 3: aids 20,30,20 (cart, cart, click)
+    aid = np.array([10, 20, 10, 30, 20, 30, 20, 30, 20], dtype=np.uint32)
+    ts = np.array([0, 5, 9, 12, 1000, 1000 + 86401, 2000, 2010, 2020], dtype=np.int32) + T
+    typ = np.array([0, 0, 1, 2, 0, 0, 1, 1, 0], dtype=np.uint8)
+    off = np.array([0, 4, 6, 9], dtype=np.int64)
+    return aid, ts, typ, off
+
+
+# hand-derived (see DESIGN.md "Worked example"): unit weights, multiply by 65536
+HAND = {
+    'click_weighted': {(10, 20): 1, (10, 30): 3, (20, 10): 1, (20, 30): 3 + 6, (30, 10): 1, (30, 20): 1 + 6},
+    'cart_weighted': {(10, 20): 1, (10, 30): 6, (20, 10): 1, (20, 30): 6 + 9, (30, 10): 1, (30, 20): 1 + 9},
+    'order_weighted': {(10, 20): 1, (10, 30): 6, (20, 10): 1, (20, 30): 6 + 3, (30, 10): 1, (30, 20): 1 + 3},
+    'click_cart': {(20, 10): 1, (20, 30): 1},
+    'click_order': {(10, 30): 1, (20, 30): 1},
+    'cart_order': {(10, 30): 1, (30, 10): 1, (20, 30): 1, (30, 20): 1},
+    'click_click': {(10, 20): 1, (20, 10): 1},
+}
+# time_weighted: t0 = T, t1 = T + 87401; extra(ts) = (196608 * (ts - t0)) // 87401
+HAND_TIME = {(10, 20): Q, (10, 30): Q, (20, 10): Q + 11, (20, 30): (Q + 11) + (Q + 4498),
+             (30, 10): Q + 26, (30, 20): (Q + 26) + (Q + 4521)}
+
+
+def test_hand_computed_micro_sessions():
+    aid, ts, typ, off = _micro()
+    for fn in (co.covis_pairs_python, lambda *a: {k: dict(zip(zip(v[0].tolist(), v[1].tolist()), v[2].tolist()))
+                                                  for k, v in co.covis_pairs_numpy(*a).items()}):
+        got = fn(aid, ts, typ, off, co.CovisSpec())
+        for kind, want in HAND.items():
+            assert got[kind] == {p: w * Q for p, w in want.items()}, kind
+        assert got['time_weighted'] == HAND_TIME
+
+
+@pytest.mark.parametrize('seed,n_aids', [(1, 200), (2, 30), (3, 5000)])
+def test_python_and_numpy_restatements_agree(seed, n_aids):
+    ev = generate_sessions(250, n_aids=n_aids, seed=seed)
+    for window, gap in ((30, 86400), (4, 300)):
+        sp = co.CovisSpec(window=window, max_gap=gap)
+        st = {}
+        a = co.covis_pairs_python(ev.aid, ev.ts, ev.type, ev.sess_off, sp)
+        b = co.covis_pairs_numpy(ev.aid, ev.ts, ev.type, ev.sess_off, sp, stats=st)
+        for k in co.ALL_KINDS:
+            pa = co.pairs_dict_to_arrays(a[k])
+            assert all(np.array_equal(p, q) for p, q in zip(pa, b[k])), k
+        n_all = sum(len(co.expand_window_python(ev.aid, ev.ts, ev.type, int(ev.sess_off[s]), int(ev.sess_off[s + 1]), sp))
+                    for s in range(ev.n_sessions))
+        assert st['P'] == n_all
+
+
+def test_expand_window_order_and_attributes():
+    aid, ts, typ, off = _micro()
+    rows = co.expand_window_python(aid, ts, typ, 0, 4, co.CovisSpec(), ('click_cart', 'click_order', 'cart_order', 'click_click'), T, T + 87401)
+    # rows by first position of x (10, 20, 30), columns by first position of y
+    assert [(r[0], r[1]) for r in rows] == [(10, 20), (10, 30), (20, 10), (20, 30), (30, 10), (30, 20)]
+    assert [r[2] for r in rows] == [0, 2, 0, 2, 0, 0]                       # type_y of the first valid pair
+    assert [r[3] for r in rows] == [0b1000, 0b0110, 0b1001, 0b0010, 0b0100, 0]   # filter bits
+    assert [r[4] for r in rows] == [0, 0, 11, 11, 26, 26]                   # time extra of the first pair's x
+
+
+def test_golden_fixture_is_reproduced():
+    g = np.load(os.path.join(GOLDEN, 'covis_golden.npz'))
+    got = co.covis_topk_numpy(g['aid'], g['ts'], g['type'], g['sess_off'], co.CovisSpec(), k=20)
+    for k in co.ALL_KINDS:
+        for name, arr in zip('xyw', got[k]):
+            assert np.array_equal(arr, g[f'{k}_{name}']), (k, name)
+
+
+def test_topk_tie_break_and_truncation():
+    x = np.array([1, 1, 1, 1, 2], dtype=np.uint32)
+    y = np.array([9, 3, 5, 7, 1], dtype=np.uint32)
+    W = np.array([5, 7, 7, 5, 1], dtype=np.uint64)
+    rx, ry, rw = co.topk_rows(x, y, W, k=3)
+    assert ry.tolist() == [3, 5, 7, 1] and rw.tolist() == [7, 7, 5, 1] and rx.tolist() == [1, 1, 1, 2]
+    assert co.wgt_float32(np.array([65536 * 3 + 32768], dtype=np.uint64)).tolist() == [3.5]
+
+
+def test_window_is_the_session_tail():
+    aid = np.arange(40, dtype=np.uint32)
+    ts = (T + np.arange(40)).astype(np.int32)
+    typ = np.zeros(40, dtype=np.uint8)
+    off = np.array([0, 40], dtype=np.int64)
+    got = co.covis_pairs_numpy(aid, ts, typ, off, co.CovisSpec(window=30, kinds=('click_click',)))['click_click']
+    assert got[0].min() == 10 and len(got[0]) == 30 * 29

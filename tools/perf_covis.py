@@ -1,0 +1,36 @@
+"""Exploratory timing of the covisitation pipeline on one GPU (not the bench contract)."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from otto_amd.synth import generate_sessions_torch, OTTO_N_AIDS
+from otto_amd.covisitation.engine import CovisBuilder
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--sessions', type=int, default=1_000_000)
+ap.add_argument('--kinds', default='click_weighted,cart_weighted,order_weighted')
+ap.add_argument('--reps', type=int, default=3)
+ap.add_argument('--l-cap', type=int, default=0)
+ap.add_argument('--k', type=int, default=20)
+a = ap.parse_args()
+dev = torch.device('cuda:0')
+t = time.time()
+d = generate_sessions_torch(a.sessions, device=dev)
+torch.cuda.synchronize()
+print(f'gen {time.time()-t:.1f}s  E={d["aid"].numel()}', flush=True)
+kinds = tuple(a.kinds.split(','))
+b = CovisBuilder(OTTO_N_AIDS, kinds=kinds, ts_min=int(d['ts'].min()), ts_max=int(d['ts'].max()), device=dev)
+if a.l_cap:
+    b.set_option('l_cap', a.l_cap)
+for r in range(a.reps):
+    b.reset()
+    torch.cuda.synchronize(); t0 = time.time()
+    b.feed(d['aid'], d['ts'], d['type'], d['sess_off'])
+    torch.cuda.synchronize(); t1 = time.time()
+    out = b.finalize(k=a.k)
+    torch.cuda.synchronize(); t2 = time.time()
+    st = b.stats(); tm = b.timings()
+    print(f'rep {r}: feed {1e3*(t1-t0):.1f} ms  finalize {1e3*(t2-t1):.1f} ms  total {1e3*(t2-t0):.1f} ms  '
+          f'pairs/s {st["pairs"]/(t2-t0):.3e}', flush=True)
+    print('   stats', st, flush=True)
+    print('   timings(ms)', {k: round(v, 3) for k, v in tm.items()}, flush=True)
+print('mem GB', torch.cuda.max_memory_allocated()/1e9)
