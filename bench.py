@@ -210,7 +210,7 @@ def main():
     if not a.no_mf:
         try:
             from otto_amd.matrix_factorization import bench_mf
-        except ModuleNotFoundError:
+        except ImportError:
             bench_mf = None
         if bench_mf is not None:
             del builder, eng, out
