@@ -57,6 +57,17 @@ SIGNATURES = {
     'otto_covis_import_runs': (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     'otto_covis_copy_records': (_i32, [_vp, _vp, _vp, _vp, _vp]),
     'otto_covis_timings': (_i32, [_vp, C.POINTER(C.c_float)]),
+    # include/otto_mf.h
+    'otto_mf_create': (_i32, [C.POINTER(_vp), _i64, _i64, _i32, _i64, _i32]),
+    'otto_mf_destroy': (None, [_vp]),
+    'otto_mf_forward': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    'otto_mf_eval': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    'otto_mf_step_sparse_adam': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32,
+                                        C.c_double, C.c_double, C.c_double, C.c_double, _i64, _vp, _vp]),
+    'otto_mf_bpr_step': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_uint64, C.c_uint64, _i64, C.c_float, C.c_float,
+                                _i32, _vp, _vp, _vp]),
+    'otto_mf_score_topk': (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _i64, _vp]),
+    'otto_mf_score_workspace': (_i64, [_i64, _i64, _i32]),
 }
 
 _lib = None

@@ -1,0 +1,202 @@
+"""GPU parity tests of the MF kernels (through the C-ABI) against the reference-pinned golden
+vectors and the CPU oracle. Floating point: tolerance 1e-4 relative (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+
+import mf_oracle as mo
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return np.load(os.path.join(GOLDEN, 'mf_golden.npz'))
+
+
+def _t(a, dev, dtype=None):
+    import torch
+    x = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return x.to(dtype) if dtype is not None else x
+
+
+@pytest.mark.parametrize('p,loss_kind,shared', [('mf_', 0, False), ('cf_', 1, True)])
+def test_sparse_adam_training_matches_reference_golden(gold, gpu_device, p, loss_kind, shared):
+    """Whole golden run (3 epochs, StepLR per batch, duplicate rows in every batch) step by step."""
+    import torch
+    from otto_amd.matrix_factorization.engine import MFEngine
+    g = gold
+    n1, n2, d, B, nb, ne, step_size = g[p + 'hyper'].tolist()
+    lr0 = float(g[p + 'lr'])
+    eng = MFEngine(n1, n2, d, B, shared_table=shared, device=gpu_device)
+    E1 = _t(g[p + 'w1_0'], gpu_device)
+    E2 = E1 if shared else _t(g[p + 'w2_0'], gpu_device)
+    m1, v1 = torch.zeros_like(E1), torch.zeros_like(E1)
+    m2, v2 = (m1, v1) if shared else (torch.zeros_like(E2), torch.zeros_like(E2))
+    i1, i2, tg = _t(g[p + 'i1'], gpu_device), _t(g[p + 'i2'], gpu_device), _t(g[p + 'target'], gpu_device)
+    losses = torch.zeros(ne * nb, dtype=torch.float32, device=gpu_device)
+    val = torch.zeros(ne * nb, dtype=torch.float32, device=gpu_device)
+    preds = torch.zeros(ne, nb * B, dtype=torch.float32, device=gpu_device)
+    t = 0
+    for e in range(ne):
+        for b in range(nb):
+            lr = lr0 * 0.5 ** (t // step_size)
+            t += 1
+            eng.step_sparse_adam(E1, m1, v1, E2, m2, v2, i1[b], i2[b], tg[b], loss_kind, lr, (0.9, 0.999), 1e-8, t,
+                                 losses[t - 1:t])
+            if t == 1:
+                np.testing.assert_allclose(E1.cpu().numpy(), g[p + 'step_w1'], rtol=RTOL, atol=1e-6)
+                np.testing.assert_allclose(m1.cpu().numpy(), g[p + 'step_m1'], rtol=RTOL, atol=1e-7)
+                np.testing.assert_allclose(v1.cpu().numpy(), g[p + 'step_v1'], rtol=RTOL, atol=1e-9)
+                if not shared:
+                    np.testing.assert_allclose(E2.cpu().numpy(), g[p + 'step_w2'], rtol=RTOL, atol=1e-6)
+                    np.testing.assert_allclose(v2.cpu().numpy(), g[p + 'step_v2'], rtol=RTOL, atol=1e-9)
+        for b in range(nb):
+            eng.eval(E1, E2, i1[b], i2[b], tg[b], loss_kind, val[e * nb + b:e * nb + b + 1], preds[e, b * B:(b + 1) * B])
+    losses, val = losses.cpu().numpy().astype(np.float64), val.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(losses, g[p + 'step_loss'], rtol=RTOL)
+    np.testing.assert_allclose(losses.reshape(ne, nb).mean(1), g[p + 'epoch_train_loss'], rtol=RTOL)
+    np.testing.assert_allclose(val.reshape(ne, nb).mean(1), g[p + 'epoch_val_loss'], rtol=RTOL)
+    np.testing.assert_allclose(E1.cpu().numpy(), g[p + 'w1_T'], rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(m1.cpu().numpy(), g[p + 'm1_T'], rtol=1e-3, atol=1e-6)
+    tgt = g[p + 'target'].reshape(-1).astype(np.float64)
+    pr = preds.cpu().numpy().astype(np.float64)
+    if not shared:
+        np.testing.assert_allclose(np.abs(pr - tgt).mean(1), g[p + 'epoch_val_s0'], rtol=RTOL)
+        np.testing.assert_allclose(((pr - tgt) ** 2).mean(1), g[p + 'epoch_val_s1'], rtol=RTOL)
+    # owner words must all be released after every step (otherwise the next step mis-coalesces)
+    eng2 = MFEngine(n1, n2, d, B, shared_table=shared, device=gpu_device)
+    del eng2
+
+
+@pytest.mark.parametrize('d', [4, 8, 16, 32, 64, 128, 256])
+def test_forward_all_factor_sizes(gpu_device, d):
+    from otto_amd.matrix_factorization.engine import MFEngine
+    rng = np.random.default_rng(d)
+    n1, n2, B = 500, 300, 1000
+    E1 = rng.standard_normal((n1, d)).astype(np.float32)
+    E2 = rng.standard_normal((n2, d)).astype(np.float32)
+    i1, i2 = rng.integers(0, n1, B), rng.integers(0, n2, B)
+    eng = MFEngine(n1, n2, d, B, device=gpu_device)
+    out = eng.forward(_t(E1, gpu_device), _t(E2, gpu_device), _t(i1, gpu_device), _t(i2, gpu_device)).cpu().numpy()
+    want = (E1[i1].astype(np.float64) * E2[i2].astype(np.float64)).sum(1)
+    np.testing.assert_allclose(out, want, rtol=RTOL, atol=1e-5)
+
+
+@pytest.mark.parametrize('d,B', [(64, 4096), (32, 1000), (128, 513)])
+def test_sparse_adam_large_batch_with_heavy_duplicates_vs_oracle(gpu_device, d, B):
+    import torch
+    from otto_amd.matrix_factorization.engine import MFEngine
+    rng = np.random.default_rng(B)
+    n1, n2 = 3000, 200
+    E1 = (rng.standard_normal((n1, d)) * 0.3).astype(np.float32)
+    E2 = (rng.standard_normal((n2, d)) * 0.3).astype(np.float32)
+    st = [np.zeros_like(E1), np.zeros_like(E1), np.zeros_like(E2), np.zeros_like(E2)]
+    dv = [_t(x, gpu_device) for x in (E1, st[0], st[1], E2, st[2], st[3])]
+    eng = MFEngine(n1, n2, d, B, device=gpu_device)
+    loss = torch.zeros(3, device=gpu_device)
+    want = []
+    for step in range(1, 4):
+        i1 = rng.integers(0, n1, B)
+        i2 = np.minimum(rng.zipf(1.3, B) - 1, n2 - 1)      # one aid holds a large share of the batch
+        tg = rng.integers(0, 3, B)
+        eng.step_sparse_adam(dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], _t(i1, gpu_device), _t(i2, gpu_device),
+                             _t(tg, gpu_device), 0, 0.05, (0.9, 0.999), 1e-8, step, loss[step - 1:step])
+        want.append(mo.sparse_adam_step(E1, st[0], st[1], E2, st[2], st[3], i1, i2, tg, 'MSELoss', 0.05, step=step)[0])
+    np.testing.assert_allclose(loss.cpu().numpy(), want, rtol=RTOL)
+    for got, ref in zip(dv, (E1, st[0], st[1], E2, st[2], st[3])):
+        # element-wise 1e-3 / 2e-5 (Adam's m / (sqrt(v) + eps) amplifies fp32 summation-order noise on
+        # near-zero gradients) and 1e-4 relative in norm, the stated tolerance
+        a = got.cpu().numpy()
+        np.testing.assert_allclose(a, ref, rtol=1e-3, atol=2e-5)
+        assert np.linalg.norm(a - ref) <= RTOL * np.linalg.norm(ref)
+
+
+def test_bpr_negatives_and_batch_step_vs_oracle(gpu_device):
+    import torch
+    from otto_amd.matrix_factorization.engine import MFEngine, BPR_BATCH
+    rng = np.random.default_rng(9)
+    nu, ni, d, B = 5000, 400, 64, 3000
+    U = (rng.standard_normal((nu, d)) * 0.2).astype(np.float32)
+    V = (rng.standard_normal((ni, d)) * 0.2).astype(np.float32)
+    u = rng.integers(0, nu, B)
+    i = np.minimum(rng.zipf(1.4, B) - 1, ni - 1)
+    eng = MFEngine(nu, ni, d, B, device=gpu_device)
+    dU, dV = _t(U, gpu_device), _t(V, gpu_device)
+    neg = torch.zeros(B, dtype=torch.int64, device=gpu_device)
+    for epoch in range(2):
+        ls = eng.bpr_step(dU, dV, _t(u, gpu_device), _t(i, gpu_device), seed=42, epoch=epoch, row0=12345, lr=0.05, l2=0.01,
+                          mode=BPR_BATCH, neg_out=neg)
+        j = mo.bpr_negatives(42, epoch, 12345, i, ni)
+        assert np.array_equal(neg.cpu().numpy(), j), 'negative sampler differs from the oracle (integer work: bit-exact)'
+        want = mo.bpr_step_batch(U, V, u, i, j, 0.05, 0.01)
+        np.testing.assert_allclose(ls.item(), want, rtol=RTOL)
+        np.testing.assert_allclose(dU.cpu().numpy(), U, rtol=RTOL, atol=1e-6)
+        np.testing.assert_allclose(dV.cpu().numpy(), V, rtol=RTOL, atol=1e-6)
+
+
+def test_bpr_hogwild_equals_oracle_on_race_free_batch_and_learns(gpu_device):
+    import torch
+    from otto_amd.matrix_factorization.engine import MFEngine, BPR_HOGWILD
+    rng = np.random.default_rng(10)
+    nu, ni, d, B = 4096, 100000, 32, 2048
+    U = (rng.standard_normal((nu, d)) * 0.2).astype(np.float32)
+    V = (rng.standard_normal((ni, d)) * 0.2).astype(np.float32)
+    u = rng.permutation(nu)[:B]
+    i = rng.permutation(ni)[:B]
+    # keep a prefix of the batch whose positives and sampled negatives share no row: no races -> deterministic
+    j = mo.bpr_negatives(1, 0, 0, i, ni)
+    seen, keep = set(), 0
+    for a, b in zip(i.tolist(), j.tolist()):
+        if a in seen or b in seen:
+            break
+        seen.update((a, b))
+        keep += 1
+    assert keep >= 64
+    u, i, j = u[:keep], i[:keep], j[:keep]
+    eng = MFEngine(nu, ni, d, B, device=gpu_device)
+    dU, dV = _t(U, gpu_device), _t(V, gpu_device)
+    ls = eng.bpr_step(dU, dV, _t(u, gpu_device), _t(i, gpu_device), seed=1, epoch=0, row0=0, lr=0.1, mode=BPR_HOGWILD)
+    want = mo.bpr_step_sequential(U, V, u, i, j, 0.1)
+    np.testing.assert_allclose(ls.item(), want, rtol=RTOL)
+    np.testing.assert_allclose(dU.cpu().numpy(), U, rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(dV.cpu().numpy(), V, rtol=RTOL, atol=1e-6)
+    # statistical check with races: popular items repeat, loss must still go down epoch over epoch
+    i2 = _t(np.minimum(rng.zipf(1.3, B) - 1, ni - 1), gpu_device)
+    u2 = _t(rng.integers(0, nu, B), gpu_device)
+    curve = [eng.bpr_step(dU, dV, u2, i2, seed=3, epoch=0, row0=0, lr=0.2, mode=BPR_HOGWILD).item() for _ in range(30)]
+    assert curve[-1] < 0.7 * curve[0]
+
+
+@pytest.mark.parametrize('B,N,d,k,pad', [(300, 5000, 64, 20, 0), (129, 777, 32, 7, -1), (64, 40000, 128, 20, 0), (5, 50, 8, 32, 3)])
+def test_score_topk_matches_oracle(gpu_device, B, N, d, k, pad):
+    from otto_amd.matrix_factorization.engine import score_topk
+    rng = np.random.default_rng(N)
+    U = rng.standard_normal((B, d)).astype(np.float32)
+    V = rng.standard_normal((N, d)).astype(np.float32)
+    ids, sc = score_topk(_t(U, gpu_device), _t(V, gpu_device), k=k, pad_col=pad)
+    wi, ws = mo.score_topk(U, V, k=k, pad_col=pad)
+    np.testing.assert_allclose(sc.cpu().numpy(), ws, rtol=RTOL, atol=1e-5)
+    got = ids.cpu().numpy()
+    # ids may differ only where the fp32 scores are within rounding of each other
+    diff = got != wi
+    if diff.any():
+        S = U.astype(np.float64) @ V.astype(np.float64).T
+        rows = np.nonzero(diff)[0]
+        assert np.allclose(S[rows, got[diff]], S[rows, wi[diff]], rtol=RTOL, atol=1e-5)
+    if pad >= 0:
+        assert (got != pad).all()
+
+
+def test_score_topk_exact_ties_prefer_smaller_id(gpu_device):
+    from otto_amd.matrix_factorization.engine import score_topk
+    U = np.zeros((130, 8), dtype=np.float32)
+    U[:, 0] = 1
+    V = np.zeros((3000, 8), dtype=np.float32)
+    V[:, 0] = (np.arange(3000) % 7 == 0)          # many exact ties at score 1 and 0
+    ids, sc = score_topk(_t(U, gpu_device), _t(V, gpu_device), k=20, pad_col=0)
+    want = [7 * (q + 1) for q in range(20)]
+    assert (ids.cpu().numpy() == np.array(want)).all() and (sc.cpu().numpy() == 1).all()
