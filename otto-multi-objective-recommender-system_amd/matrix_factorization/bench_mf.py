@@ -1,0 +1,150 @@
+"""MF half of bench.py's metric: BPR triplets/s (hogwild SGD, the north star's mode) on the
+OTTO-shape (session, aid) stream, plus the reference-config R-MF (SparseAdam) samples/s.
+
+Weak scaling for N > 1: every rank owns ``--mf-rows`` rows of its own session chunk (user rows are
+rank-private), the item table is replicated and its deltas are all-reduced over RCCL every
+``SYNC_EVERY`` launches (``bpr.sync_item_table``)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROWS_PER_LAUNCH = 1 << 24
+SYNC_EVERY = 4
+HBM_PEAK_GBS = 8000.0
+
+
+def _cpu_baseline(U, V, users, items, n_items, sample):
+    """PyTorch-CPU restatement of the BPR batch step (oracle/mf_oracle.py arithmetic) on a bounded sample."""
+    import torch
+    ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import mf_oracle as mo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    u = users[:sample].cpu()
+    i = items[:sample].cpu()
+    uu, inv = torch.unique(u, return_inverse=True)          # only the touched user rows travel to the host
+    Uc = U[uu.to(U.device)].cpu()
+    Vc = V.cpu()
+    t0 = time.time()
+    j = torch.from_numpy(mo.bpr_negatives(42, 0, 0, i.numpy()[:20000], n_items))       # sampler rate measured on 20k rows
+    t_neg = (time.time() - t0) / 20000 * sample
+    j = torch.randint(0, n_items, (sample,))
+    t0 = time.time()
+    eu, ei, ej = Uc[inv], Vc[i], Vc[j]
+    x = (eu * (ei - ej)).sum(1)
+    s = torch.sigmoid(-x)[:, None]
+    Uc.index_add_(0, inv, 0.05 * s * (ei - ej))
+    Vc.index_add_(0, i, 0.05 * s * eu)
+    Vc.index_add_(0, j, -0.05 * s * eu)
+    dt = time.time() - t0
+    return {'value': round(sample / dt, 1), 'unit': 'triplets/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{sample} triplets of the same stream, PyTorch-CPU gather/dot/sigmoid/index_add_ '
+                      f'({dt:.2f} s; pure-Python counter RNG of the oracle excluded: {t_neg:.1f} s extrapolated)'}
+
+
+def run(a, dev, rank, world):
+    import torch
+    import torch.distributed as dist
+    from ..synth import generate_sessions_torch, OTTO_N_AIDS, OTTO_N_SESSIONS
+    from .engine import MFEngine, BPR_HOGWILD
+    from .bpr import sync_item_table
+    d = a.mf_factors
+    n_users, n_items = (OTTO_N_SESSIONS if a.sessions >= OTTO_N_SESSIONS else a.sessions), OTTO_N_AIDS
+    data = generate_sessions_torch(n_users, n_aids=n_items, seed=142 + rank, device=dev)
+    E = data['aid'].numel()
+    rows = min(a.mf_rows, E)
+    lens = data['sess_off'][1:] - data['sess_off'][:-1]
+    users = torch.repeat_interleave(torch.arange(n_users, device=dev), lens, output_size=E)
+    perm = torch.randperm(E, device=dev)[:rows]            # SGD visits rows in random order
+    users = users[perm].contiguous()
+    items = data['aid'].to(torch.int64)[perm].contiguous()
+    del data, perm, lens
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    U = (torch.randn(n_users, d, device=dev, generator=g) * 0.1).contiguous()
+    V = (torch.randn(n_items, d, device=dev, generator=g) * 0.1).contiguous()
+    V_snap = V.clone() if world > 1 else None
+    eng = MFEngine(n_users, n_items, d, ROWS_PER_LAUNCH, device=dev)
+    n_launch = (rows + ROWS_PER_LAUNCH - 1) // ROWS_PER_LAUNCH
+    loss = torch.zeros(n_launch, device=dev)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_launch)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_launch)]
+
+    def epoch(e, timed):
+        for q in range(n_launch):
+            lo, hi = q * ROWS_PER_LAUNCH, min(rows, (q + 1) * ROWS_PER_LAUNCH)
+            if timed:
+                ev0[q].record()
+            eng.bpr_step(U, V, users[lo:hi], items[lo:hi], 42, e, lo, 0.05, 0.0, BPR_HOGWILD, loss_sum=loss[q:q + 1])
+            if timed:
+                ev1[q].record()
+            if world > 1 and ((q + 1) % SYNC_EVERY == 0 or q == n_launch - 1):
+                sync_item_table(V, V_snap)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.bpr_step(U, V, users[:ROWS_PER_LAUNCH], items[:ROWS_PER_LAUNCH], 42, 99, 0, 0.05, 0.0, BPR_HOGWILD, loss_sum=loss[:1])
+    first_loss = None
+    barrier()
+    t0 = time.perf_counter()
+    kms = 0.0
+    for e in range(a.steps):
+        epoch(e, True)
+        torch.cuda.synchronize()
+        kms += sum(s.elapsed_time(t) for s, t in zip(ev0, ev1))
+        if first_loss is None:
+            first_loss = float(loss.sum().item()) / rows
+    barrier()
+    dt = time.perf_counter() - t0
+    last_loss = float(loss.sum().item()) / rows
+    if world > 1:
+        mx = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dt = float(mx.item())
+    total = rows * a.steps * world
+    per_triplet = 16 + 6 * 4 * d        # two int64 indices + three fp32 rows read and written back
+    launch_ms = kms / (a.steps * n_launch)
+    gbs = per_triplet * (rows / n_launch) / (launch_ms * 1e-3) / 1e9
+    res = {
+        'metric': 'BPR triplets/sec MF train', 'value': round(total / dt, 1), 'unit': 'triplets/s',
+        'ms_per_epoch': round(1e3 * dt / a.steps, 3), 'epochs': a.steps, 'dtype': 'f32',
+        'config': {'workload': f'BPR-MF hogwild SGD, {n_users} sessions x {n_items} aids x {d}-d fp32, {rows} (session, aid) rows per GPU '
+                               f'in random order, uniform negatives from the counter RNG, launches of {ROWS_PER_LAUNCH}',
+                   'rows_per_gpu': rows, 'factors': d,
+                   'parallelism': 'single GPU' if world == 1 else f'data-parallel x{world}: user rows private, item-table deltas all-reduced (RCCL) every {SYNC_EVERY} launches'},
+        'roofline': {'kernel': 'k_bpr_hogwild', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'avg_ms': round(launch_ms, 4),
+                     'algorithmic_bytes': int(per_triplet * (rows / n_launch))},
+        'mean_loss_first_epoch': round(first_loss, 5), 'mean_loss_last_epoch': round(last_loss, 5),
+    }
+    if rank == 0 and world == 1:
+        # reference-config R-MF: MSELoss + SparseAdam, 32 factors, batch 262,144 (models/matrix_factorization/config.yaml)
+        B, dr = 262144, 32
+        E1 = torch.randn(n_users, dr, device=dev, generator=g)
+        E2 = torch.randn(n_items + 1, dr, device=dev, generator=g)
+        st = [torch.zeros_like(E1), torch.zeros_like(E1), torch.zeros_like(E2), torch.zeros_like(E2)]
+        er = MFEngine(n_users, n_items + 1, dr, B, device=dev)
+        tg = torch.randint(0, 3, (rows,), device=dev)
+        lo_ = torch.zeros(1, device=dev)
+        nb = min(40, rows // B)
+        for w in range(2):
+            er.step_sparse_adam(E1, st[0], st[1], E2, st[2], st[3], users[:B], items[:B], tg[:B], 0, 0.05, (0.9, 0.999), 1e-8, w + 1, lo_)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for b in range(nb):
+            sl = slice(b * B, (b + 1) * B)
+            er.step_sparse_adam(E1, st[0], st[1], E2, st[2], st[3], users[sl], items[sl], tg[sl], 0, 0.05, (0.9, 0.999), 1e-8, b + 3, lo_)
+        torch.cuda.synchronize()
+        dtr = time.perf_counter() - t1
+        res['rmf_sparse_adam'] = {'value': round(nb * B / dtr, 1), 'unit': 'samples/s', 'ms_per_batch': round(1e3 * dtr / nb, 3),
+                                  'config': f'MatrixFactorization MSELoss SparseAdam, {dr} factors, batch {B} (reference config.yaml)'}
+        del E1, E2, st, er
+        if a.cpu_sessions > 0:
+            res['cpu_baseline'] = _cpu_baseline(U, V, users, items, n_items, 2_000_000)
+    return res

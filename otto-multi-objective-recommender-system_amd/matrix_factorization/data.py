@@ -1,0 +1,104 @@
+"""Batch loader and dataset builders of the MF trainer.
+
+* :class:`DeviceBatchLoader` replaces the Merlin GPU loader the reference uses
+  (``torch_trainer.py:315-318``: ``Loader(dataset, batch_size, shuffle=True, drop_last=False)``):
+  the whole parquet sits in HBM (223.6M rows x 3 x int64 = 5.4 GB of 288 GB) and every epoch
+  yields ``(dict_of_int64_device_tensors, None)`` batches in a fresh random order.
+* ``build_sessions_aids`` / ``build_aid_pairs`` restate the dataset builders of
+  ``torch_trainer.py:190-260, 286-287`` (App. E defects not reproduced).
+"""
+import numpy as np
+import torch
+
+
+class DeviceBatchLoader:
+
+    def __init__(self, columns, batch_size, shuffle=True, drop_last=False, device='cuda:0', seed=None):
+        self.device = torch.device(device)
+        self.columns = {k: (v if torch.is_tensor(v) else torch.from_numpy(np.array(v, dtype=np.int64))).to(
+            device=self.device, dtype=torch.int64).contiguous() for k, v in columns.items()}
+        self.n = next(iter(self.columns.values())).numel()
+        self.batch_size, self.shuffle, self.drop_last = int(batch_size), shuffle, drop_last
+        self.gen = torch.Generator(device=self.device)
+        if seed is not None:
+            self.gen.manual_seed(seed)
+
+    @classmethod
+    def from_parquet(cls, path, batch_size, shuffle=True, drop_last=False, device='cuda:0', seed=None):
+        import pyarrow.parquet as pq
+        table = pq.read_table(str(path))
+        return cls({name: table.column(name).to_numpy() for name in table.column_names if not name.startswith('__')},
+                   batch_size, shuffle, drop_last, device, seed)
+
+    def __len__(self):
+        return self.n // self.batch_size if self.drop_last else (self.n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        perm = torch.randperm(self.n, device=self.device, generator=self.gen) if self.shuffle else None
+        for b in range(len(self)):
+            lo, hi = b * self.batch_size, min(self.n, (b + 1) * self.batch_size)
+            if perm is None:
+                yield {k: v[lo:hi] for k, v in self.columns.items()}, None
+            else:
+                idx = perm[lo:hi]
+                yield {k: v[idx] for k, v in self.columns.items()}, None
+
+
+def build_sessions_aids(df):
+    """``torch_trainer.py:286-287``: (session, aid, target = type), int64."""
+    out = df.rename(columns={'type': 'target'})[['session', 'aid', 'target']].astype('int64')
+    return out
+
+
+def build_aid_pairs(df, sampling_strategy='diff', chunk_size=30000, hour_difference=1, target_aggregation='mean',
+                    sample_frac=0.15, seed=42):
+    """Labelled aid pairs (x1, x2, target) of ``torch_trainer.py:190-260``.
+
+    'diff' (``:229-255``): per session x1 = aid, x2 = next aid (positive), x3 = a random aid of the
+    same session (negative); (x1, x2) target 1 and (x1, x3) target 0 with x2 != x3, x1 != x2 / x1 != x3;
+    de-duplicated, positives win over negatives.  'time' (``:190-227``): per session-chunk self-join of a
+    row sample, drop aid_x == aid_y, target = 0 < dt <= hour_difference hours, aggregated per pair by
+    mean >= 0.5 or max.  The reference's sampling/shuffle is unseeded; here it is seeded.
+    """
+    import pandas as pd
+    rng = np.random.default_rng(seed)
+    df = df.sort_values(['session', 'ts'], kind='stable').reset_index(drop=True)
+    if sampling_strategy == 'diff':
+        s = df['session'].to_numpy()
+        a = df['aid'].to_numpy().astype(np.int64)
+        same_next = np.r_[s[1:] == s[:-1], False]
+        x2 = np.r_[a[1:], -1]
+        key = rng.random(len(a))
+        order = np.lexsort((key, s))                 # random permutation inside each session
+        x3 = a[order]
+        ok = same_next
+        pos = ok & (x2 != x3) & (a != x2) & (a != x3)
+        neg = ok & (x2 != x3) & (a != x3)
+        P = pd.DataFrame({'x1': a[pos], 'x2': x2[pos], 'target': 1}).drop_duplicates(['x1', 'x2'])
+        N = pd.DataFrame({'x1': a[neg], 'x2': x3[neg], 'target': 0}).drop_duplicates(['x1', 'x2'])
+        out = pd.concat((P, N), ignore_index=True).drop_duplicates(['x1', 'x2'], keep='first')
+    elif sampling_strategy == 'time':
+        sessions = df['session'].unique()
+        parts = []
+        for i in range(0, len(sessions), chunk_size):
+            lo, hi = sessions[i], sessions[min(len(sessions) - 1, i + chunk_size - 1)]
+            c = df[(df['session'] >= lo) & (df['session'] <= hi)]
+            c = c.sample(frac=sample_frac, random_state=int(rng.integers(2 ** 31)))
+            m = c.merge(c, on='session')
+            m = m[m['aid_x'] != m['aid_y']]
+            dt = (m['ts_y'] - m['ts_x']).to_numpy().astype(np.float64) / 3600.0
+            parts.append(pd.DataFrame({'aid_x': m['aid_x'].to_numpy(), 'aid_y': m['aid_y'].to_numpy(),
+                                       'target': ((dt > 0) & (dt <= hour_difference)).astype(np.int64)}))
+        allp = pd.concat(parts, ignore_index=True)
+        grp = allp.groupby(['aid_x', 'aid_y'])['target']
+        if target_aggregation == 'mean':
+            out = grp.mean().reset_index()
+            out['target'] = (out['target'] >= 0.5).astype(int)
+        elif target_aggregation == 'max':
+            out = grp.max().reset_index()
+        else:
+            raise ValueError('Invalid target aggregation')
+        out = out.rename(columns={'aid_x': 'x1', 'aid_y': 'x2'})
+    else:
+        raise ValueError('Invalid sampling strategy')
+    return out.astype('int64').reset_index(drop=True)
