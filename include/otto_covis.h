@@ -54,7 +54,7 @@ typedef struct otto_covis_params {
     int32_t n_filters;     /* 0..4 pair-filter kinds                                    */
     uint16_t filter_mask[OTTO_COVIS_MAX_FILTERS];              /* bit (type_x*3+type_y) */
     int32_t n_type_weights;                                    /* 0..4 type-weighted kinds */
-    int32_t type_weight[OTTO_COVIS_MAX_TYPE_WEIGHTS][3];       /* Wk[type_y] > 0        */
+    int32_t type_weight[OTTO_COVIS_MAX_TYPE_WEIGHTS][3];       /* Wk[type_y] in 1..255  */
 } otto_covis_params;
 
 typedef struct otto_covis_ctx otto_covis_ctx;
@@ -111,7 +111,8 @@ int otto_covis_finalize(otto_covis_ctx* ctx, int group, int k, uint32_t* d_out_y
 int otto_covis_stats(otto_covis_ctx* ctx, int64_t* out /* [OTTO_COVIS_STAT_COUNT] */);
 
 /* Tuning knobs; results are exact for every value.
- *   "l_cap": expanded pairs per hash partition of a heavy aid_x (default 6144). */
+ *   "l_cap": expanded pairs per hash partition of a heavy aid_x (default 6144);
+ *   "partition": 1 (default) bucket heavy aids' pairs by partition once, 0 re-read and filter per partition. */
 int otto_covis_set_option(otto_covis_ctx* ctx, const char* name, int64_t value);
 
 /*
@@ -139,6 +140,7 @@ enum {
     OTTO_COVIS_T_WINSCAN = 0,
     OTTO_COVIS_T_EXPAND,     /* K1 pair-expand            */
     OTTO_COVIS_T_INDEX,      /* histogram + scan + scatter + item lists */
+    OTTO_COVIS_T_PARTITION,  /* heavy aids: count + scan + scatter of records into hash-partition buckets */
     OTTO_COVIS_T_REDUCE_S,
     OTTO_COVIS_T_REDUCE_M,
     OTTO_COVIS_T_REDUCE_L,

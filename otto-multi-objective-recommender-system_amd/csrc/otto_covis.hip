@@ -19,6 +19,7 @@
 
 #include <stdarg.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 namespace otto {
@@ -248,7 +249,8 @@ __global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
 // ---------------------------------------------------------------------------
 // index: histogram / scatter of runs by aid_x, work items
 // ---------------------------------------------------------------------------
-constexpr uint64_t CNT_REC_MASK = (1ull << 40) - 1;   // cnt64[x] = runs << 40 | records
+constexpr int CNT_REC_BITS = 36;                      // cnt64[x] = runs << 36 | records
+constexpr uint64_t CNT_REC_MASK = (1ull << CNT_REC_BITS) - 1;
 
 __global__ void k_hist_runs(const uint32_t* run_x, const uint64_t* run_desc, int64_t n_slots, uint64_t* cnt64,
                             uint32_t n_aids) {
@@ -257,14 +259,14 @@ __global__ void k_hist_runs(const uint32_t* run_x, const uint64_t* run_desc, int
         const uint64_t len = d & 0xFFull;
         if (len) {
             const uint32_t x = run_x[i];
-            if (x < n_aids) atomicAdd((unsigned long long*)&cnt64[x], (unsigned long long)((1ull << 40) | len));
+            if (x < n_aids) atomicAdd((unsigned long long*)&cnt64[x], (unsigned long long)((1ull << CNT_REC_BITS) | len));
         }
     }
 }
 
 struct RunCount {
     const uint64_t* cnt64;
-    __device__ uint64_t operator()(int64_t x) const { return cnt64[x] >> 40; }
+    __device__ uint64_t operator()(int64_t x) const { return cnt64[x] >> CNT_REC_BITS; }
 };
 struct RecCount {
     const uint64_t* cnt64;
@@ -332,7 +334,7 @@ struct BinRuns {     // runs of aid x if it falls in bin `bin`
     __device__ uint64_t operator()(int64_t x) const {
         const uint64_t n = cnt64[x] & CNT_REC_MASK;
         const int b = n <= (uint64_t)S_CAP ? 0 : (n <= (uint64_t)M_CAP ? 1 : 2);
-        return b == bin ? (cnt64[x] >> 40) : 0;
+        return b == bin ? (cnt64[x] >> CNT_REC_BITS) : 0;
     }
 };
 
@@ -354,15 +356,20 @@ __global__ void k_fill_items(ItemCount f, uint32_t n_aids, const uint64_t* item_
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
 constexpr int MAX_K = 32;
 constexpr int MAX_KINDS = 4;
+constexpr int PART_CHUNK_RUNS = 1024;   // runs per partition-pass work item
+constexpr int PART_LDS_LOG2R = 12;      // partitions whose histogram / cursors fit LDS
 
 struct ReduceArgs {
     const uint64_t* items;
     uint32_t n_items;
-    const uint64_t* cnt64;         // [n_aids] runs << 40 | records
+    const uint64_t* cnt64;         // [n_aids] runs << 36 | records
     const uint64_t* run_start;     // [n_aids+1]
     const uint64_t* sorted_desc;
     const uint32_t* rec;
     const uint32_t* tw;
+    const uint64_t* pstart;        // [n_items+1] partition buckets of L items with R > 1 (null: filter mode)
+    const uint32_t* prec;
+    const uint32_t* ptw;
     int group;
     int nk;                        // kinds selected in this pass (<= MAX_KINDS)
     int k;
@@ -382,38 +389,251 @@ struct ReduceArgs {
     uint32_t l_cap;                // records per L partition the item lists were sized for
 };
 
-__device__ __forceinline__ bool cand_better(uint64_t w1, uint32_t y1, uint64_t w2, uint32_t y2) {
-    return w1 > w2 || (w1 == w2 && y1 < y2);
-}
+// ---- candidate keys: "better" = larger weight, then smaller aid_y ---------------------------------------
+// KeyN: one 64-bit word  unit_weight << 26 | (2^26-1 - aid_y)  (unit weight < 2^36: < 2^28 sessions x weight < 256)
+// KeyW: (Q16 weight u64, aid_y) for the time-weighted kind whose weight needs up to 46 bits
+struct KeyN { uint64_t c; };
+struct KeyW { uint64_t w; uint32_t y; };
 
-// Wave-wide sorted top list: lane i holds the i-th best (w == 0: empty). Push one candidate per lane.
-__device__ __forceinline__ void wave_topk_push(uint64_t& bw, uint32_t& by, uint64_t cw, uint32_t cy, int k) {
+__device__ __forceinline__ bool kbetter(KeyN a, KeyN b) { return a.c > b.c; }
+__device__ __forceinline__ bool kbetter(KeyW a, KeyW b) { return a.w > b.w || (a.w == b.w && a.y < b.y); }
+__device__ __forceinline__ bool kvalid(KeyN a) { return a.c != 0; }
+__device__ __forceinline__ bool kvalid(KeyW a) { return a.w != 0; }
+__device__ __forceinline__ void kclear(KeyN& a) { a.c = 0; }
+__device__ __forceinline__ void kclear(KeyW& a) { a.w = 0; a.y = KEY_EMPTY; }
+__device__ __forceinline__ KeyN kshfl(KeyN a, int src) { return {(uint64_t)__shfl((unsigned long long)a.c, src, 64)}; }
+__device__ __forceinline__ KeyW kshfl(KeyW a, int src) { return {(uint64_t)__shfl((unsigned long long)a.w, src, 64), (uint32_t)__shfl(a.y, src, 64)}; }
+__device__ __forceinline__ KeyN kshfl_xor(KeyN a, int m) { return {(uint64_t)__shfl_xor((unsigned long long)a.c, m, 64)}; }
+__device__ __forceinline__ KeyW kshfl_xor(KeyW a, int m) { return {(uint64_t)__shfl_xor((unsigned long long)a.w, m, 64), (uint32_t)__shfl_xor(a.y, m, 64)}; }
+__device__ __forceinline__ KeyN kshfl_up(KeyN a) { return {(uint64_t)__shfl_up((unsigned long long)a.c, 1, 64)}; }
+__device__ __forceinline__ KeyW kshfl_up(KeyW a) { return {(uint64_t)__shfl_up((unsigned long long)a.w, 1, 64), (uint32_t)__shfl_up(a.y, 1, 64)}; }
+__device__ __forceinline__ void kmake(KeyN& k, uint64_t unit_w, uint64_t, uint32_t y) { k.c = unit_w ? (unit_w << REC_AID_BITS) | (uint64_t)(REC_AID_MASK - y) : 0; }
+__device__ __forceinline__ void kmake(KeyW& k, uint64_t, uint64_t q16_w, uint32_t y) { k.w = q16_w; k.y = q16_w ? y : KEY_EMPTY; }
+__device__ __forceinline__ uint64_t kweight(KeyN k) { return (k.c >> REC_AID_BITS) * 65536ull; }
+__device__ __forceinline__ uint64_t kweight(KeyW k) { return k.w; }
+__device__ __forceinline__ uint32_t kaid(KeyN k) { return REC_AID_MASK - (uint32_t)(k.c & REC_AID_MASK); }
+__device__ __forceinline__ uint32_t kaid(KeyW k) { return k.y; }
+// storage of partial lists: (u64, u32)
+__device__ __forceinline__ void kstore(KeyN k, uint64_t* w, uint32_t* y) { *w = k.c; *y = 0; }
+__device__ __forceinline__ void kstore(KeyW k, uint64_t* w, uint32_t* y) { *w = k.w; *y = k.y; }
+__device__ __forceinline__ void kload(KeyN& k, uint64_t w, uint32_t) { k.c = w; }
+__device__ __forceinline__ void kload(KeyW& k, uint64_t w, uint32_t y) { k.w = w; k.y = w ? y : KEY_EMPTY; }
+
+// Wave-wide sorted top list: lane i holds the i-th best. Insert the per-lane candidates that beat the k-th.
+template <typename K>
+__device__ __forceinline__ void wave_topk_push(K& best, K cand, int k) {
     const unsigned l = lane_id();
-    uint64_t tw = __shfl(bw, k - 1, 64);
-    uint32_t tyy = __shfl(by, k - 1, 64);
-    uint64_t m = __ballot(cw != 0 && cand_better(cw, cy, tw, tyy));
+    K thr = kshfl(best, k - 1);
+    uint64_t m = __ballot(kvalid(cand) && kbetter(cand, thr));
     while (m) {
         const int src = __ffsll((unsigned long long)m) - 1;
-        const uint64_t w = __shfl(cw, src, 64);
-        const uint32_t y = __shfl(cy, src, 64);
-        const uint64_t upw = __shfl_up(bw, 1, 64);
-        const uint32_t upy = __shfl_up(by, 1, 64);
-        if (cand_better(w, y, bw, by)) {
-            if (l > 0 && cand_better(w, y, upw, upy)) { bw = upw; by = upy; }
-            else { bw = w; by = y; }
-        }
-        tw = __shfl(bw, k - 1, 64);
-        tyy = __shfl(by, k - 1, 64);
+        const K c = kshfl(cand, src);
+        const K up = kshfl_up(best);
+        if (kbetter(c, best)) best = (l > 0 && kbetter(c, up)) ? up : c;
+        thr = kshfl(best, k - 1);
         m &= m - 1;
-        m &= __ballot(cw != 0 && cand_better(cw, cy, tw, tyy));
+        m &= __ballot(kvalid(cand) && kbetter(cand, thr));
     }
 }
 
+// 64-lane bitonic sort, best first
+template <typename K>
+__device__ __forceinline__ void wave_bitonic_sort_desc(K& v) {
+    const unsigned l = lane_id();
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const K o = kshfl_xor(v, j);
+            const bool keep_better = ((l & j) == 0) == ((l & k) == 0);
+            if (keep_better ? kbetter(o, v) : kbetter(v, o)) v = o;
+        }
+    }
+}
+
+// Top-k of MPL register-resident candidates per lane: lane-local best -> 64-wide bitonic sort -> only the
+// few candidates that still beat the k-th entry are inserted one by one. Result: lane i = i-th best.
+template <int MPL, typename K>
+__device__ __forceinline__ void wave_topk_select(K (&c)[MPL], int k, K& best) {
+    K lb = c[0];
+    int bi = 0;
+#pragma unroll
+    for (int i = 1; i < MPL; ++i)
+        if (kbetter(c[i], lb)) { lb = c[i]; bi = i; }
+#pragma unroll
+    for (int i = 0; i < MPL; ++i)
+        if (i == bi) kclear(c[i]);
+    best = lb;
+    wave_bitonic_sort_desc(best);
+    if (MPL > 1) {
+        for (;;) {
+            const K thr = kshfl(best, k - 1);
+            kclear(lb);
+            bi = -1;
+#pragma unroll
+            for (int i = 0; i < MPL; ++i)
+                if (kvalid(c[i]) && (bi < 0 || kbetter(c[i], lb))) { lb = c[i]; bi = i; }
+            const bool q = bi >= 0 && kbetter(lb, thr);
+            if (__ballot(q) == 0) break;
+#pragma unroll
+            for (int i = 0; i < MPL; ++i)
+                if (i == bi) kclear(c[i]);
+            if (!q) kclear(lb);
+            wave_topk_push(best, lb, k);
+        }
+    }
+}
+
+// Visit every record of the runs [r0, r1). Runs are dealt round-robin to the NW waves of the workgroup
+// (wave w owns runs r0 + w, r0 + w + NW, ...): a wave fetches 64 of its run descriptors with one load, then
+// walks them two at a time (one per 32-lane half) with GATHER_U record loads in flight per lane, so an item
+// of a few dozen runs costs two or three dependent memory round trips instead of one per run.
+constexpr int GATHER_U = 8;
+template <int NW, typename F>
+__device__ __forceinline__ void for_each_record(const uint64_t* sorted_desc, const uint32_t* rec, uint64_t r0, uint64_t r1,
+                                                int wid, F f) {
+    const unsigned lane = lane_id();
+    const uint32_t l = lane & 31u;
+    const int half = (int)(lane >> 5);
+    for (uint64_t cb = r0; cb < r1; cb += (uint64_t)NW * 64) {
+        const uint64_t mine = cb + (uint64_t)lane * NW + wid;
+        const uint64_t d = mine < r1 ? sorted_desc[mine] : 0ull;
+        const uint64_t left = r1 - cb;                                   // runs in this chunk (all waves)
+        const int nrun = left >= (uint64_t)NW * 64 ? 64 : (int)((left + NW - 1 - wid) / NW);   // this wave's share
+        for (int t = 0; t < nrun; t += 2 * GATHER_U) {
+            uint32_t rc[GATHER_U];
+            uint64_t sl[GATHER_U];
+            bool ok[GATHER_U];
+#pragma unroll
+            for (int u = 0; u < GATHER_U; ++u) {
+                const int src = t + 2 * u + half;
+                const uint64_t dd = (uint64_t)__shfl((unsigned long long)d, src & 63, 64);
+                sl[u] = (dd >> 8) + l;
+                ok[u] = src < 64 && l < (uint32_t)(dd & 0xFFull);
+                rc[u] = ok[u] ? rec[sl[u]] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < GATHER_U; ++u)
+                if (ok[u]) f(rc[u], sl[u]);
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t rec_hash(uint32_t rc) { return (rc & REC_AID_MASK) * 0x9E3779B1u; }
+
+// ---- partition pass for heavy aids (L items with R > 1): count, then scatter into per-partition buckets ----
+struct PartArgs {
+    const uint64_t* chunks;        // x | chunk << 26
+    uint32_t n_chunks;
+    const uint64_t* cnt64;
+    const uint8_t* boost;
+    const uint64_t* run_start;
+    const uint64_t* sorted_desc;
+    const uint32_t* rec;
+    const uint32_t* tw;
+    const uint64_t* litem_start;   // [n_aids+1] first L item of aid x
+    uint32_t* pcount;              // [n_items_L]
+    uint32_t* pcursor;
+    const uint64_t* pstart;        // [n_items_L + 1]
+    uint32_t* prec;
+    uint32_t* ptw;
+    uint32_t l_cap;
+};
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_partition(PartArgs a) {
+    constexpr int NW = 4;
+    constexpr int RL = 1 << PART_LDS_LOG2R;
+    __shared__ uint32_t s_cnt[RL];
+    __shared__ uint64_t s_base[SCATTER ? RL : 1];
+    const int wid = threadIdx.x >> 6;
+    for (uint32_t ci = blockIdx.x; ci < a.n_chunks; ci += gridDim.x) {
+        const uint64_t ch = a.chunks[ci];
+        const uint32_t x = (uint32_t)(ch & REC_AID_MASK);
+        const uint64_t c = ch >> 26;
+        const int lgR = l_log2r(a.cnt64[x] & CNT_REC_MASK, a.boost[x], a.l_cap);
+        const uint32_t R = 1u << lgR, pmask = R - 1u;
+        const int pshift = 32 - L_LOG2T - lgR;
+        const uint64_t g0 = a.litem_start[x];
+        const uint64_t rb = a.run_start[x] + c * PART_CHUNK_RUNS;
+        uint64_t re = rb + PART_CHUNK_RUNS;
+        if (re > a.run_start[x + 1]) re = a.run_start[x + 1];
+        if (lgR > PART_LDS_LOG2R) {
+            // more partitions than LDS counters: global atomics per record (giant aids only)
+            for_each_record<NW>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t slot) {
+                const uint64_t g = g0 + ((rec_hash(rc) >> pshift) & pmask);
+                if (!SCATTER) atomicAdd(&a.pcount[g], 1u);
+                else {
+                    const uint64_t pos = a.pstart[g] + atomicAdd(&a.pcursor[g], 1u);
+                    a.prec[pos] = rc;
+                    if (a.ptw) a.ptw[pos] = a.tw[slot];
+                }
+            });
+            continue;
+        }
+        for (uint32_t p = threadIdx.x; p < R; p += 256) s_cnt[p] = 0;
+        __syncthreads();
+        for_each_record<NW>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t) {
+            atomicAdd(&s_cnt[(rec_hash(rc) >> pshift) & pmask], 1u);
+        });
+        __syncthreads();
+        if (!SCATTER) {
+            for (uint32_t p = threadIdx.x; p < R; p += 256) {
+                const uint32_t n = s_cnt[p];
+                if (n) atomicAdd(&a.pcount[g0 + p], n);
+            }
+        } else {
+            for (uint32_t p = threadIdx.x; p < R; p += 256) {
+                const uint32_t n = s_cnt[p];
+                if (n) s_base[p] = a.pstart[g0 + p] + atomicAdd(&a.pcursor[g0 + p], n);
+                s_cnt[p] = 0;
+            }
+            __syncthreads();
+            for_each_record<NW>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t slot) {
+                const uint32_t p = (rec_hash(rc) >> pshift) & pmask;
+                const uint64_t pos = s_base[p] + atomicAdd(&s_cnt[p], 1u);
+                a.prec[pos] = rc;
+                if (a.ptw) a.ptw[pos] = a.tw[slot];
+            });
+        }
+        __syncthreads();
+    }
+}
+
+struct PCount {
+    const uint32_t* pcount;
+    __device__ uint64_t operator()(int64_t i) const { return pcount[i]; }
+};
+
+struct ChunkCount {   // partition-pass work items of aid x: ceil(runs / PART_CHUNK_RUNS) if it is an L aid with R > 1
+    const uint64_t* cnt64;
+    const uint8_t* boost;
+    const uint32_t* flag;
+    int only_flagged;
+    uint32_t l_cap;
+    __device__ uint64_t operator()(int64_t x) const {
+        const uint64_t n = cnt64[x] & CNT_REC_MASK;
+        if (n <= (uint64_t)M_CAP) return 0;
+        if (only_flagged && !flag[x]) return 0;
+        if (l_log2r(n, boost[x], l_cap) == 0) return 0;
+        return ((cnt64[x] >> CNT_REC_BITS) + PART_CHUNK_RUNS - 1) / PART_CHUNK_RUNS;
+    }
+};
+
+__global__ void k_fill_chunks(ChunkCount f, uint32_t n_aids, const uint64_t* chunk_start, uint64_t* chunks) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n_aids) return;
+    const uint64_t c = f((int64_t)x);
+    const uint64_t s = chunk_start[x];
+    for (uint64_t q = 0; q < c; ++q) chunks[s + q] = (uint64_t)x | (q << 26);
+}
+
+// ---- the reduce kernel --------------------------------------------------------------------------------
 template <int LOG2T, int THREADS, int GROUP>
 __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
     constexpr int T = 1 << LOG2T;
     constexpr int NW = THREADS / 64;
-    constexpr int NHW = THREADS / 32;
+    using K = typename std::conditional<GROUP == OTTO_COVIS_GROUP_TIME, KeyW, KeyN>::type;
     __shared__ uint32_t s_key[T];
     __shared__ uint32_t s_v[3][T];
     __shared__ uint64_t s_cw[MAX_KINDS][NW][MAX_K];
@@ -421,7 +641,6 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
     __shared__ uint32_t s_item;
     __shared__ uint32_t s_ovf;
 
-    const int hw = threadIdx.x >> 5, l = threadIdx.x & 31;
     const int wid = threadIdx.x >> 6;
     const unsigned lane = lane_id();
     uint32_t it = blockIdx.x;
@@ -450,52 +669,63 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
         if (threadIdx.x == 0) s_ovf = 0;
         __syncthreads();
 
-        const uint64_t rb = a.run_start[x], re = a.run_start[x + 1];
-        for (uint64_t r = rb + hw; r < re; r += NHW) {
-            const uint64_t d = a.sorted_desc[r];
-            const uint32_t len = (uint32_t)(d & 0xFFull);
-            const uint64_t off = d >> 8;
-            if ((uint32_t)l < len) {
-                const uint32_t rc = a.rec[off + l];
-                const uint32_t y = rc & REC_AID_MASK;
-                const uint32_t h = y * 0x9E3779B1u;
-                bool take = lgR == 0 || ((h >> pshift) & pmask) == part;
-                uint32_t add0 = 0, add1 = 0, add2 = 0;
-                if (GROUP == OTTO_COVIS_GROUP_TYPE) {
-                    const uint32_t tyj = (rc >> REC_AID_BITS) & 3u;
-                    add0 = tyj == 0; add1 = tyj == 1; add2 = tyj == 2;
-                } else if (GROUP == OTTO_COVIS_GROUP_FILTER) {
-                    const uint32_t fb = (rc >> 28) >> a.chan_shift;
-                    add0 = fb & 1u; add1 = (fb >> 1) & 1u; add2 = (fb >> 2) & 1u;
-                    take = take && (add0 | add1 | add2);
-                }
-                if (take) {
-                    uint32_t slot = h >> (32 - LOG2T);
-                    int found = -1;
-                    for (int probe = 0; probe < T; ++probe) {
-                        const uint32_t kx = s_key[slot];
-                        if (kx == y) { found = (int)slot; break; }
-                        if (kx == KEY_EMPTY) {
-                            const uint32_t old = atomicCAS(&s_key[slot], KEY_EMPTY, y);
-                            if (old == KEY_EMPTY || old == y) { found = (int)slot; break; }
-                        }
-                        slot = (slot + 1) & (T - 1);
-                    }
-                    if (found < 0) {
-                        s_ovf = 1;
-                    } else if (GROUP == OTTO_COVIS_GROUP_TIME) {
-                        const uint32_t e = a.tw[off + l];
-                        atomicAdd(&s_v[0][found], 1u);
-                        const uint32_t old = atomicAdd(&s_v[1][found], e);
-                        if (old + e < old) atomicAdd(&s_v[2][found], 1u);
-                    } else {
-                        if (add0) atomicAdd(&s_v[0][found], 1u);
-                        if (add1) atomicAdd(&s_v[1][found], 1u);
-                        if (add2) atomicAdd(&s_v[2][found], 1u);
-                    }
-                }
+        // one record into the table; `e` = time extra (GROUP_TIME only)
+        auto insert = [&](uint32_t rc, uint32_t h, uint32_t e) {
+            const uint32_t y = rc & REC_AID_MASK;
+            uint32_t add0 = 0, add1 = 0, add2 = 0;
+            if (GROUP == OTTO_COVIS_GROUP_TYPE) {
+                const uint32_t tyj = (rc >> REC_AID_BITS) & 3u;
+                add0 = tyj == 0; add1 = tyj == 1; add2 = tyj == 2;
+            } else if (GROUP == OTTO_COVIS_GROUP_FILTER) {
+                const uint32_t fb = (rc >> 28) >> a.chan_shift;
+                add0 = fb & 1u; add1 = (fb >> 1) & 1u; add2 = (fb >> 2) & 1u;
+                if (!(add0 | add1 | add2)) return;
             }
-            if (lgR > 0 && s_ovf) break;
+            uint32_t slot = h >> (32 - LOG2T);
+            int found = -1;
+            for (int probe = 0; probe < T; ++probe) {
+                const uint32_t kx = s_key[slot];
+                if (kx == y) { found = (int)slot; break; }
+                if (kx == KEY_EMPTY) {
+                    const uint32_t old = atomicCAS(&s_key[slot], KEY_EMPTY, y);
+                    if (old == KEY_EMPTY || old == y) { found = (int)slot; break; }
+                }
+                slot = (slot + 1) & (T - 1);
+            }
+            if (found < 0) { s_ovf = 1; return; }
+            if (GROUP == OTTO_COVIS_GROUP_TIME) {
+                atomicAdd(&s_v[0][found], 1u);
+                const uint32_t old = atomicAdd(&s_v[1][found], e);
+                if (old + e < old) atomicAdd(&s_v[2][found], 1u);
+            } else {
+                if (add0) atomicAdd(&s_v[0][found], 1u);
+                if (add1) atomicAdd(&s_v[1][found], 1u);
+                if (add2) atomicAdd(&s_v[2][found], 1u);
+            }
+        };
+
+        if (lgR > 0 && a.pstart) {
+            // heavy aid, records already bucketed by hash partition: contiguous coalesced reads
+            const uint64_t ps = a.pstart[it], pe = a.pstart[it + 1];
+            for (uint64_t i0 = ps + threadIdx.x; i0 < pe; i0 += 4 * THREADS) {
+                uint32_t rc[4], e[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint64_t i = i0 + (uint64_t)u * THREADS;
+                    rc[u] = i < pe ? a.prec[i] : KEY_EMPTY;
+                    e[u] = (GROUP == OTTO_COVIS_GROUP_TIME && i < pe) ? a.ptw[i] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (rc[u] != KEY_EMPTY) insert(rc[u], rec_hash(rc[u]), e[u]);
+                if (s_ovf) break;
+            }
+        } else {
+            for_each_record<NW>(a.sorted_desc, a.rec, a.run_start[x], a.run_start[x + 1], wid, [&](uint32_t rc, uint64_t slot) {
+                const uint32_t h = rec_hash(rc);
+                if (lgR == 0 || ((h >> pshift) & pmask) == part)
+                    insert(rc, h, GROUP == OTTO_COVIS_GROUP_TIME ? a.tw[slot] : 0u);
+            });
         }
         __syncthreads();
         const bool ovf = s_ovf != 0;
@@ -507,51 +737,58 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
                 atomicAdd(a.ovf_count, 1u);
             }
         } else {
-            // ---- per-wave top-k over a slice of the table, per kind ------------------------
-            for (int j = 0; j < a.nk; ++j) {
-                uint64_t bw = 0;
-                uint32_t by = 0;
-                for (int i = wid * 64 + (int)lane; i < T; i += NW * 64) {
-                    const uint32_t y = s_key[i];
-                    uint64_t w = 0;
-                    if (y != KEY_EMPTY) {
-                        if (GROUP == OTTO_COVIS_GROUP_TIME)
-                            w = 65536ull * s_v[0][i] + (((uint64_t)s_v[2][i] << 32) | s_v[1][i]);
-                        else
-                            w = 65536ull * ((uint64_t)s_v[0][i] * a.coef[j][0] + (uint64_t)s_v[1][i] * a.coef[j][1] +
-                                            (uint64_t)s_v[2][i] * a.coef[j][2]);
+            // ---- per-wave top-k over a slice of the table (MPL slots per lane), per kind --------
+            constexpr int MPL = T / THREADS;
+            constexpr int MPLM = (NW * MAX_K + 63) / 64;
+            K fin[MAX_KINDS];
+#pragma unroll
+            for (int j = 0; j < MAX_KINDS; ++j) {
+                kclear(fin[j]);
+                if (j < a.nk) {
+                    K c[MPL];
+#pragma unroll
+                    for (int q = 0; q < MPL; ++q) {
+                        const int i = q * THREADS + threadIdx.x;
+                        const uint32_t y = s_key[i];
+                        uint64_t uw = 0, qw = 0;
+                        if (y != KEY_EMPTY) {
+                            if (GROUP == OTTO_COVIS_GROUP_TIME)
+                                qw = 65536ull * s_v[0][i] + (((uint64_t)s_v[2][i] << 32) | s_v[1][i]);
+                            else
+                                uw = (uint64_t)s_v[0][i] * a.coef[j][0] + (uint64_t)s_v[1][i] * a.coef[j][1] +
+                                     (uint64_t)s_v[2][i] * a.coef[j][2];
+                        }
+                        kmake(c[q], uw, qw, y);
                     }
-                    wave_topk_push(bw, by, w, y, a.k);
+                    wave_topk_select<MPL, K>(c, a.k, fin[j]);
+                    if (NW > 1 && (int)lane < a.k) kstore(fin[j], &s_cw[j][wid][lane], &s_cy[j][wid][lane]);
                 }
-                if ((int)lane < a.k) { s_cw[j][wid][lane] = bw; s_cy[j][wid][lane] = by; }
             }
-            __syncthreads();
+            if (NW > 1) __syncthreads();
             // ---- merge the NW partial lists: wave (j % NW) finishes kind j ------------------
-            for (int j = wid; j < a.nk; j += NW) {
-                uint64_t bw = 0;
-                uint32_t by = 0;
-                if (NW == 1) {
-                    bw = (int)lane < a.k ? s_cw[j][0][lane] : 0;
-                    by = (int)lane < a.k ? s_cy[j][0][lane] : 0;
-                } else {
-                    for (int c0 = 0; c0 < NW * a.k; c0 += 64) {
-                        const int c = c0 + (int)lane;
-                        uint64_t w = 0;
-                        uint32_t y = 0;
-                        if (c < NW * a.k) { w = s_cw[j][c / a.k][c % a.k]; y = s_cy[j][c / a.k][c % a.k]; }
-                        wave_topk_push(bw, by, w, y, a.k);
+#pragma unroll
+            for (int j = 0; j < MAX_KINDS; ++j) {
+                if (j >= a.nk || (j % NW) != wid) continue;
+                K best = fin[j];
+                if (NW > 1) {
+                    K c[MPLM];
+#pragma unroll
+                    for (int q = 0; q < MPLM; ++q) {
+                        const int ci = q * 64 + (int)lane;
+                        kclear(c[q]);
+                        if (ci < NW * a.k) kload(c[q], s_cw[j][ci / a.k][ci % a.k], s_cy[j][ci / a.k][ci % a.k]);
                     }
+                    wave_topk_select<MPLM, K>(c, a.k, best);
                 }
-                const bool valid = (int)lane < a.k && bw != 0;
+                const bool valid = (int)lane < a.k && kvalid(best);
                 if (lgR == 0) {
                     const size_t o = ((size_t)(a.kind_base + j) * a.n_aids + x) * (size_t)a.k + lane;
-                    if (valid) { a.out_y[o] = by; a.out_w[o] = bw; }
+                    if (valid) { a.out_y[o] = kaid(best); a.out_w[o] = kweight(best); }
                     const int nvalid = __popcll(__ballot(valid));
                     if (lane == 0) a.out_n[(size_t)(a.kind_base + j) * a.n_aids + x] = nvalid;
                 } else if ((int)lane < a.k) {
                     const size_t o = ((size_t)it * a.nk + j) * (size_t)a.k + lane;
-                    a.part_y[o] = by;
-                    a.part_w[o] = bw;
+                    kstore(best, &a.part_w[o], &a.part_y[o]);
                 }
             }
         }
@@ -563,7 +800,9 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
 }
 
 // merge the R partial top-k lists of one heavy aid (item with part == 0 and R > 1): one wave per item
+template <int GROUP>
 __global__ __launch_bounds__(64) void k_merge(ReduceArgs a) {
+    using K = typename std::conditional<GROUP == OTTO_COVIS_GROUP_TIME, KeyW, KeyN>::type;
     const uint32_t it = blockIdx.x;
     if (it >= a.n_items) return;
     const uint64_t item = a.items[it];
@@ -575,22 +814,21 @@ __global__ __launch_bounds__(64) void k_merge(ReduceArgs a) {
     const unsigned lane = lane_id();
     const uint64_t ncand = (uint64_t)a.k << lgR;
     for (int j = 0; j < a.nk; ++j) {
-        uint64_t bw = 0;
-        uint32_t by = 0;
+        K best;
+        kclear(best);
         for (uint64_t c0 = 0; c0 < ncand; c0 += 64) {
             const uint64_t c = c0 + lane;
-            uint64_t w = 0;
-            uint32_t y = 0;
+            K cand;
+            kclear(cand);
             if (c < ncand) {
                 const size_t o = ((size_t)(it + c / a.k) * a.nk + j) * (size_t)a.k + (c % a.k);
-                w = a.part_w[o];
-                y = a.part_y[o];
+                kload(cand, a.part_w[o], a.part_y[o]);
             }
-            wave_topk_push(bw, by, w, y, a.k);
+            wave_topk_push(best, cand, a.k);
         }
-        const bool valid = (int)lane < a.k && bw != 0;
+        const bool valid = (int)lane < a.k && kvalid(best);
         const size_t o = ((size_t)(a.kind_base + j) * a.n_aids + x) * (size_t)a.k + lane;
-        if (valid) { a.out_y[o] = by; a.out_w[o] = bw; }
+        if (valid) { a.out_y[o] = kaid(best); a.out_w[o] = kweight(best); }
         const int nvalid = __popcll(__ballot(valid));
         if (lane == 0) a.out_n[(size_t)(a.kind_base + j) * a.n_aids + x] = nvalid;
     }
@@ -675,6 +913,10 @@ struct otto_covis_ctx {
     uint64_t bin_pairs[3] = {0, 0, 0};
     uint64_t bin_runs[3] = {0, 0, 0};
     uint64_t n_pairs = 0, n_runs = 0;
+    // partition pass of heavy aids
+    DevBuf litem_start, chunks, pcount, pcursor, pstart, prec, ptw;
+    uint64_t n_chunks = 0;
+    int partition = 1;
     // reduce scratch
     DevBuf part_y, part_w;
     DevBuf exp_run_pos, exp_rec_pos;
@@ -704,7 +946,7 @@ extern "C" int otto_covis_create(otto_covis_ctx** out, const otto_covis_params* 
     OTTO_REQUIRE(p->ts_max >= p->ts_min, "ts_max < ts_min");
     for (int j = 0; j < p->n_type_weights; ++j)
         for (int t = 0; t < 3; ++t)
-            OTTO_REQUIRE(p->type_weight[j][t] > 0 && p->type_weight[j][t] < 65536, "type_weight[%d][%d] must be in [1, 65535]", j, t);
+            OTTO_REQUIRE(p->type_weight[j][t] > 0 && p->type_weight[j][t] < 256, "type_weight[%d][%d] must be in [1, 255]", j, t);
     for (int f = 0; f < p->n_filters; ++f) OTTO_REQUIRE(p->filter_mask[f] < 512, "filter_mask[%d] has bits above 8", f);
     otto_covis_ctx* c = new (std::nothrow) otto_covis_ctx();
     OTTO_REQUIRE(c, "out of host memory");
@@ -721,7 +963,8 @@ extern "C" void otto_covis_destroy(otto_covis_ctx* c) {
     if (!c) return;
     DevBuf* all[] = {&c->rec, &c->tw, &c->run_x, &c->run_desc, &c->pair_base, &c->ev_base, &c->partial, &c->cnt64,
                      &c->run_start, &c->cursor, &c->sorted_desc, &c->item_start, &c->boost, &c->flag, &c->counters,
-                     &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->exp_run_pos, &c->exp_rec_pos};
+                     &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->exp_run_pos, &c->exp_rec_pos,
+                     &c->litem_start, &c->chunks, &c->pcount, &c->pcursor, &c->pstart, &c->prec, &c->ptw};
     for (DevBuf* b : all) b->release();
     if (c->ev_ok)
         for (int i = 0; i < 2 * OTTO_COVIS_T_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
@@ -807,6 +1050,23 @@ static int build_items(otto_covis_ctx* c, int bin, int only_flagged, hipStream_t
         k_fill_items<<<(n_aids + 255) / 256, 256, 0, s>>>(f, n_aids, c->item_start.as<uint64_t>(), c->items[bin].as<uint64_t>());
         OTTO_HIP(hipGetLastError());
     }
+    if (bin == 2) {
+        // heavy aids: first L item of every aid + the work items of the partition pass
+        OTTO_TRY(c->litem_start.ensure((size_t)(n_aids + 1) * 8, 0, s));
+        OTTO_HIP(hipMemcpyAsync(c->litem_start.p, c->item_start.p, (size_t)(n_aids + 1) * 8, hipMemcpyDeviceToDevice, s));
+        ChunkCount cf{c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(), c->flag.as<uint32_t>(), only_flagged, c->l_cap};
+        OTTO_TRY(device_scan(cf, (int64_t)n_aids, c->item_start.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+        uint64_t nch = 0;
+        OTTO_HIP(hipMemcpyAsync(&nch, c->item_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
+        OTTO_HIP(hipStreamSynchronize(s));
+        OTTO_REQUIRE(nch < (1ull << 32), "too many partition chunks");
+        c->n_chunks = nch;
+        if (nch) {
+            OTTO_TRY(c->chunks.ensure((size_t)nch * 8, 0, s));
+            k_fill_chunks<<<(n_aids + 255) / 256, 256, 0, s>>>(cf, n_aids, c->item_start.as<uint64_t>(), c->chunks.as<uint64_t>());
+            OTTO_HIP(hipGetLastError());
+        }
+    }
     return 0;
 }
 
@@ -882,13 +1142,41 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
         k_reduce<M_LOG2T, M_THREADS, GROUP><<<grid, M_THREADS, 0, s>>>(a);
         tend(c, OTTO_COVIS_T_REDUCE_M, s);
     } else {
+        a.pstart = nullptr;
+        if (c->partition && c->n_chunks) {
+            // bucket the records of heavy aids by hash partition once (count -> scan -> scatter)
+            tbegin(c, OTTO_COVIS_T_PARTITION, s);
+            const bool time = GROUP == OTTO_COVIS_GROUP_TIME;
+            OTTO_TRY(c->pcount.ensure((size_t)a.n_items * 4, 0, s));
+            OTTO_TRY(c->pcursor.ensure((size_t)a.n_items * 4, 0, s));
+            OTTO_TRY(c->pstart.ensure((size_t)(a.n_items + 1) * 8, 0, s));
+            OTTO_TRY(c->prec.ensure((size_t)(c->bin_pairs[2] ? c->bin_pairs[2] : 1) * 4, 0, s));
+            if (time) OTTO_TRY(c->ptw.ensure((size_t)(c->bin_pairs[2] ? c->bin_pairs[2] : 1) * 4, 0, s));
+            OTTO_TRY(c->partial.ensure(scan_partial_bytes((int64_t)a.n_items), 0, s));
+            OTTO_HIP(hipMemsetAsync(c->pcount.p, 0, (size_t)a.n_items * 4, s));
+            OTTO_HIP(hipMemsetAsync(c->pcursor.p, 0, (size_t)a.n_items * 4, s));
+            PartArgs pa{c->chunks.as<uint64_t>(), (uint32_t)c->n_chunks, c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(),
+                        c->run_start.as<uint64_t>(), c->sorted_desc.as<uint64_t>(), c->rec.as<uint32_t>(), c->tw.as<uint32_t>(),
+                        c->litem_start.as<uint64_t>(), c->pcount.as<uint32_t>(), c->pcursor.as<uint32_t>(),
+                        c->pstart.as<uint64_t>(), c->prec.as<uint32_t>(), time ? c->ptw.as<uint32_t>() : nullptr, c->l_cap};
+            const uint32_t pgrid = (uint32_t)(c->n_chunks < 256u * 3u ? c->n_chunks : 256u * 3u);
+            k_partition<false><<<pgrid, 256, 0, s>>>(pa);
+            OTTO_HIP(hipGetLastError());
+            OTTO_TRY(device_scan(PCount{c->pcount.as<uint32_t>()}, (int64_t)a.n_items, c->pstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+            k_partition<true><<<pgrid, 256, 0, s>>>(pa);
+            OTTO_HIP(hipGetLastError());
+            tend(c, OTTO_COVIS_T_PARTITION, s);
+            a.pstart = c->pstart.as<uint64_t>();
+            a.prec = c->prec.as<uint32_t>();
+            a.ptw = c->ptw.as<uint32_t>();
+        }
         uint32_t grid = a.n_items < 256u ? a.n_items : 256u;
         tbegin(c, OTTO_COVIS_T_REDUCE_L, s);
         k_reduce<L_LOG2T, L_THREADS, GROUP><<<grid, L_THREADS, 0, s>>>(a);
         tend(c, OTTO_COVIS_T_REDUCE_L, s);
         OTTO_HIP(hipGetLastError());
         tbegin(c, OTTO_COVIS_T_MERGE, s);
-        k_merge<<<a.n_items, 64, 0, s>>>(a);
+        k_merge<GROUP><<<a.n_items, 64, 0, s>>>(a);
         tend(c, OTTO_COVIS_T_MERGE, s);
     }
     OTTO_HIP(hipGetLastError());
@@ -988,6 +1276,12 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
         OTTO_REQUIRE(value >= 64 && value <= (1ll << 30), "l_cap out of range");
         c->l_cap = (uint32_t)value;
         c->index_valid = false;
+        return 0;
+    }
+    if (strcmp(name, "partition") == 0) {
+        // 1 (default): bucket heavy aids' records by hash partition once; 0: every partition re-reads
+        // all of its aid's records and filters (round-1 baseline, kept for A/B measurements)
+        c->partition = value != 0;
         return 0;
     }
     OTTO_REQUIRE(false, "unknown option '%s'", name);
