@@ -356,6 +356,7 @@ __global__ void k_fill_items(ItemCount f, uint32_t n_aids, const uint64_t* item_
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
 constexpr int MAX_K = 32;
 constexpr int MAX_KINDS = 4;
+constexpr int PK = 3;                    // kinds reduced per pass over the records
 constexpr int PART_CHUNK_RUNS = 1024;   // runs per partition-pass work item
 constexpr int PART_LDS_LOG2R = 12;      // partitions whose histogram / cursors fit LDS
 
@@ -387,6 +388,7 @@ struct ReduceArgs {
     uint32_t* ovf_count;
     uint32_t* work_counter;
     uint32_t l_cap;                // records per L partition the item lists were sized for
+    int debug_skip;                // diagnostics only (wrong results): 1 skip gather, 2 skip top-k, 4 skip table init
 };
 
 // ---- candidate keys: "better" = larger weight, then smaller aid_y ---------------------------------------
@@ -403,8 +405,27 @@ __device__ __forceinline__ void kclear(KeyN& a) { a.c = 0; }
 __device__ __forceinline__ void kclear(KeyW& a) { a.w = 0; a.y = KEY_EMPTY; }
 __device__ __forceinline__ KeyN kshfl(KeyN a, int src) { return {(uint64_t)__shfl((unsigned long long)a.c, src, 64)}; }
 __device__ __forceinline__ KeyW kshfl(KeyW a, int src) { return {(uint64_t)__shfl((unsigned long long)a.w, src, 64), (uint32_t)__shfl(a.y, src, 64)}; }
-__device__ __forceinline__ KeyN kshfl_xor(KeyN a, int m) { return {(uint64_t)__shfl_xor((unsigned long long)a.c, m, 64)}; }
-__device__ __forceinline__ KeyW kshfl_xor(KeyW a, int m) { return {(uint64_t)__shfl_xor((unsigned long long)a.w, m, 64), (uint32_t)__shfl_xor(a.y, m, 64)}; }
+// lane ^ m exchange. m < 16 stays inside a 16-lane row and is done with DPP moves (quad_perm, row_half_mirror,
+// row_mirror and their compositions: xor4 = quad-reverse o half-mirror, xor8 = half-mirror o row-mirror) instead
+// of an LDS-crossbar ds_bpermute; m = 16, 32 use the shuffle.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t xor_lane32(uint32_t v, int m) {
+    switch (m) {
+        case 1: return dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
+        case 2: return dpp_mov<0x4E>(v);                       // quad_perm [2,3,0,1]
+        case 4: return dpp_mov<0x1B>(dpp_mov<0x141>(v));       // quad reverse after row_half_mirror
+        case 8: return dpp_mov<0x141>(dpp_mov<0x140>(v));      // row_half_mirror after row_mirror
+        default: return (uint32_t)__shfl_xor((int)v, m, 64);
+    }
+}
+__device__ __forceinline__ uint64_t xor_lane64(uint64_t v, int m) {
+    return ((uint64_t)xor_lane32((uint32_t)(v >> 32), m) << 32) | xor_lane32((uint32_t)v, m);
+}
+__device__ __forceinline__ KeyN kshfl_xor(KeyN a, int m) { return {xor_lane64(a.c, m)}; }
+__device__ __forceinline__ KeyW kshfl_xor(KeyW a, int m) { return {xor_lane64(a.w, m), xor_lane32(a.y, m)}; }
 __device__ __forceinline__ KeyN kshfl_up(KeyN a) { return {(uint64_t)__shfl_up((unsigned long long)a.c, 1, 64)}; }
 __device__ __forceinline__ KeyW kshfl_up(KeyW a) { return {(uint64_t)__shfl_up((unsigned long long)a.w, 1, 64), (uint32_t)__shfl_up(a.y, 1, 64)}; }
 __device__ __forceinline__ void kmake(KeyN& k, uint64_t unit_w, uint64_t, uint32_t y) { k.c = unit_w ? (unit_w << REC_AID_BITS) | (uint64_t)(REC_AID_MASK - y) : 0; }
@@ -636,24 +657,42 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
     using K = typename std::conditional<GROUP == OTTO_COVIS_GROUP_TIME, KeyW, KeyN>::type;
     __shared__ uint32_t s_key[T];
     __shared__ uint32_t s_v[3][T];
-    __shared__ uint64_t s_cw[MAX_KINDS][NW][MAX_K];
-    __shared__ uint32_t s_cy[MAX_KINDS][NW][MAX_K];
+    constexpr bool WIDE = GROUP == OTTO_COVIS_GROUP_TIME;
+    constexpr int EXCAP = 64;
+    constexpr int PKD = WIDE ? 1 : PK;      // the time-weighted group has a single kind
+    __shared__ uint64_t s_lbw[NW > 1 ? PKD : 1][NW > 1 ? THREADS : 1];         // lane-best keys
+    __shared__ uint32_t s_lby[1][(NW > 1 && WIDE) ? THREADS : 1];
+    __shared__ uint64_t s_exw[NW > 1 ? PKD : 1][NW > 1 ? EXCAP : 1];           // candidates above the threshold
+    __shared__ uint32_t s_exy[1][(NW > 1 && WIDE) ? EXCAP : 1];
+    __shared__ uint64_t s_thrw[PK];
+    __shared__ uint32_t s_thry[PK];
+    __shared__ uint32_t s_nex[PK];
+    __shared__ uint32_t s_more;
     __shared__ uint32_t s_item;
     __shared__ uint32_t s_ovf;
 
     const int wid = threadIdx.x >> 6;
     const unsigned lane = lane_id();
     uint32_t it = blockIdx.x;
+    uint32_t nxt = 0;
+    bool first_item = true;
 
     for (;;) {
         if (THREADS == S_THREADS) {
             if (it >= a.n_items) break;
         } else {
+            // dynamic dequeue, one item ahead: the atomic for the NEXT item was issued while the
+            // previous one was being reduced, so its latency is off the critical path
             __syncthreads();
-            if (threadIdx.x == 0) s_item = atomicAdd(a.work_counter, 1u);
+            if (threadIdx.x == 0) {
+                if (first_item) nxt = atomicAdd(a.work_counter, 1u);
+                s_item = nxt;
+            }
             __syncthreads();
             it = s_item;
             if (it >= a.n_items) break;
+            if (threadIdx.x == 0) nxt = atomicAdd(a.work_counter, 1u);
+            first_item = false;
         }
         const uint64_t item = a.items[it];
         const uint32_t x = (uint32_t)(item & REC_AID_MASK);
@@ -662,6 +701,7 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
         const uint32_t pmask = (1u << lgR) - 1u;
         const int pshift = 32 - LOG2T - lgR;
 
+        if (!(a.debug_skip & 4))
         for (int i = threadIdx.x; i < T; i += THREADS) {
             s_key[i] = KEY_EMPTY;
             s_v[0][i] = 0; s_v[1][i] = 0; s_v[2][i] = 0;
@@ -704,7 +744,36 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
             }
         };
 
-        if (lgR > 0 && a.pstart) {
+        // key of table slot i for kind j of this pass
+        auto slot_key = [&](int i, int j) {
+            K key;
+            const uint32_t y = s_key[i];
+            uint64_t uw = 0, qw = 0;
+            if (y != KEY_EMPTY) {
+                if (GROUP == OTTO_COVIS_GROUP_TIME)
+                    qw = 65536ull * s_v[0][i] + (((uint64_t)s_v[2][i] << 32) | s_v[1][i]);
+                else
+                    uw = (uint64_t)s_v[0][i] * a.coef[j][0] + (uint64_t)s_v[1][i] * a.coef[j][1] +
+                         (uint64_t)s_v[2][i] * a.coef[j][2];
+            }
+            kmake(key, uw, qw, y);
+            return key;
+        };
+        // sorted list (lane i = i-th best) of kind j -> output rows, or this partition's partial list
+        auto emit = [&](int j, K best) {
+            const bool valid = (int)lane < a.k && kvalid(best);
+            if (lgR == 0) {
+                const size_t o = ((size_t)(a.kind_base + j) * a.n_aids + x) * (size_t)a.k + lane;
+                if (valid) { a.out_y[o] = kaid(best); a.out_w[o] = kweight(best); }
+                const int nvalid = __popcll(__ballot(valid));
+                if (lane == 0) a.out_n[(size_t)(a.kind_base + j) * a.n_aids + x] = nvalid;
+            } else if ((int)lane < a.k) {
+                const size_t o = ((size_t)it * a.nk + j) * (size_t)a.k + lane;
+                kstore(best, &a.part_w[o], &a.part_y[o]);
+            }
+        };
+        if (a.debug_skip & 1) {
+        } else if (lgR > 0 && a.pstart) {
             // heavy aid, records already bucketed by hash partition: contiguous coalesced reads
             const uint64_t ps = a.pstart[it], pe = a.pstart[it + 1];
             for (uint64_t i0 = ps + threadIdx.x; i0 < pe; i0 += 4 * THREADS) {
@@ -729,7 +798,8 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
         }
         __syncthreads();
         const bool ovf = s_ovf != 0;
-        if (ovf) {
+        if (a.debug_skip & 2) {
+        } else if (ovf) {
             // LDS table full: ask the host to redo this aid with twice the partitions
             if (threadIdx.x == 0) {
                 a.flag[x] = 1;
@@ -737,59 +807,97 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
                 atomicAdd(a.ovf_count, 1u);
             }
         } else {
-            // ---- per-wave top-k over a slice of the table (MPL slots per lane), per kind --------
             constexpr int MPL = T / THREADS;
-            constexpr int MPLM = (NW * MAX_K + 63) / 64;
-            K fin[MAX_KINDS];
+            if (NW == 1) {
+                // ---- one wave owns the whole table: select per kind, write -------------------------
 #pragma unroll
-            for (int j = 0; j < MAX_KINDS; ++j) {
-                kclear(fin[j]);
-                if (j < a.nk) {
+                for (int j = 0; j < PK; ++j) {
+                    if (j >= a.nk) continue;
                     K c[MPL];
 #pragma unroll
+                    for (int q = 0; q < MPL; ++q) c[q] = slot_key(q * THREADS + threadIdx.x, j);
+                    K best;
+                    wave_topk_select<MPL, K>(c, a.k, best);
+                    emit(j, best);
+                }
+            } else {
+                // ---- block-wide: ONE sort per kind. P1 every lane: keys of its MPL slots, lane-best to LDS.
+                //      P2 wave j: top-k of the THREADS lane-bests, publish the k-th as threshold.
+                //      P3 every lane: the (rare) other candidates above the threshold go to a small list.
+                //      P4 wave j: insert them, emit. P3/P4 repeat only if the list overflowed. -------------
+                K c[PKD][MPL];
+#pragma unroll
+                for (int j = 0; j < PKD; ++j) {
+                    if (j >= a.nk) continue;
+                    K lb;
+                    kclear(lb);
+                    int bi = 0;
+#pragma unroll
                     for (int q = 0; q < MPL; ++q) {
-                        const int i = q * THREADS + threadIdx.x;
-                        const uint32_t y = s_key[i];
-                        uint64_t uw = 0, qw = 0;
-                        if (y != KEY_EMPTY) {
-                            if (GROUP == OTTO_COVIS_GROUP_TIME)
-                                qw = 65536ull * s_v[0][i] + (((uint64_t)s_v[2][i] << 32) | s_v[1][i]);
-                            else
-                                uw = (uint64_t)s_v[0][i] * a.coef[j][0] + (uint64_t)s_v[1][i] * a.coef[j][1] +
-                                     (uint64_t)s_v[2][i] * a.coef[j][2];
+                        c[j][q] = slot_key(q * THREADS + threadIdx.x, j);
+                        if (kbetter(c[j][q], lb)) { lb = c[j][q]; bi = q; }
+                    }
+#pragma unroll
+                    for (int q = 0; q < MPL; ++q)
+                        if (q == bi) kclear(c[j][q]);
+                    kstore(lb, &s_lbw[j][threadIdx.x], &s_lby[0][WIDE ? threadIdx.x : 0]);
+                }
+                if (threadIdx.x < PK) s_nex[threadIdx.x] = 0;
+                if (threadIdx.x == 0) s_more = 0;
+                __syncthreads();
+                K best;
+                kclear(best);
+                const bool merger = wid < a.nk && wid < PKD;      // wave j finishes kind j (nk <= PK <= NW)
+                if (merger) {
+                    K lbs[NW];
+#pragma unroll
+                    for (int q = 0; q < NW; ++q)
+                        kload(lbs[q], s_lbw[wid][q * 64 + lane], s_lby[0][WIDE ? q * 64 + lane : 0]);
+                    wave_topk_select<NW, K>(lbs, a.k, best);
+                    const K thr = kshfl(best, a.k - 1);
+                    if (lane == 0) kstore(thr, &s_thrw[wid], &s_thry[wid]);
+                }
+                for (;;) {
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < PKD; ++j) {
+                        if (j >= a.nk) continue;
+                        K thr;
+                        kload(thr, s_thrw[j], s_thry[j]);
+#pragma unroll
+                        for (int q = 0; q < MPL; ++q) {
+                            if (kvalid(c[j][q]) && kbetter(c[j][q], thr)) {
+                                const uint32_t pos = atomicAdd(&s_nex[j], 1u);
+                                if (pos < (uint32_t)EXCAP) {
+                                    kstore(c[j][q], &s_exw[j][pos], &s_exy[0][WIDE ? pos : 0]);
+                                    kclear(c[j][q]);
+                                } else {
+                                    s_more = 1;
+                                }
+                            }
                         }
-                        kmake(c[q], uw, qw, y);
                     }
-                    wave_topk_select<MPL, K>(c, a.k, fin[j]);
-                    if (NW > 1 && (int)lane < a.k) kstore(fin[j], &s_cw[j][wid][lane], &s_cy[j][wid][lane]);
-                }
-            }
-            if (NW > 1) __syncthreads();
-            // ---- merge the NW partial lists: wave (j % NW) finishes kind j ------------------
-#pragma unroll
-            for (int j = 0; j < MAX_KINDS; ++j) {
-                if (j >= a.nk || (j % NW) != wid) continue;
-                K best = fin[j];
-                if (NW > 1) {
-                    K c[MPLM];
-#pragma unroll
-                    for (int q = 0; q < MPLM; ++q) {
-                        const int ci = q * 64 + (int)lane;
-                        kclear(c[q]);
-                        if (ci < NW * a.k) kload(c[q], s_cw[j][ci / a.k][ci % a.k], s_cy[j][ci / a.k][ci % a.k]);
+                    __syncthreads();
+                    const bool more = s_more != 0;
+                    if (merger) {
+                        const uint32_t n = s_nex[wid] < (uint32_t)EXCAP ? s_nex[wid] : (uint32_t)EXCAP;
+                        for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+                            K cand;
+                            kclear(cand);
+                            if (c0 + lane < n) kload(cand, s_exw[wid][c0 + lane], s_exy[0][WIDE ? c0 + lane : 0]);
+                            wave_topk_push(best, cand, a.k);
+                        }
+                        if (more) {
+                            const K thr = kshfl(best, a.k - 1);
+                            if (lane == 0) kstore(thr, &s_thrw[wid], &s_thry[wid]);
+                        }
                     }
-                    wave_topk_select<MPLM, K>(c, a.k, best);
+                    if (!more) break;
+                    __syncthreads();
+                    if (threadIdx.x < PK) s_nex[threadIdx.x] = 0;
+                    if (threadIdx.x == 0) s_more = 0;
                 }
-                const bool valid = (int)lane < a.k && kvalid(best);
-                if (lgR == 0) {
-                    const size_t o = ((size_t)(a.kind_base + j) * a.n_aids + x) * (size_t)a.k + lane;
-                    if (valid) { a.out_y[o] = kaid(best); a.out_w[o] = kweight(best); }
-                    const int nvalid = __popcll(__ballot(valid));
-                    if (lane == 0) a.out_n[(size_t)(a.kind_base + j) * a.n_aids + x] = nvalid;
-                } else if ((int)lane < a.k) {
-                    const size_t o = ((size_t)it * a.nk + j) * (size_t)a.k + lane;
-                    kstore(best, &a.part_w[o], &a.part_y[o]);
-                }
+                if (merger) emit(wid, best);
             }
         }
         if (THREADS == S_THREADS) {
@@ -917,6 +1025,7 @@ struct otto_covis_ctx {
     DevBuf litem_start, chunks, pcount, pcursor, pstart, prec, ptw;
     uint64_t n_chunks = 0;
     int partition = 1;
+    int debug_skip = 0;
     // reduce scratch
     DevBuf part_y, part_w;
     DevBuf exp_run_pos, exp_rec_pos;
@@ -1213,7 +1322,7 @@ extern "C" int otto_covis_finalize(otto_covis_ctx* c, int group, int k, uint32_t
     OTTO_HIP(hipMemsetAsync(d_out_n, 0, (size_t)n_kinds * n_aids * 4, s));
 
     // FILTER passes carry 3 channels each; TYPE passes select up to 4 weight vectors from 3 counters.
-    const int per_pass = group == OTTO_COVIS_GROUP_FILTER ? 3 : MAX_KINDS;
+    const int per_pass = PK;
     for (int kb = 0; kb < n_kinds; kb += per_pass) {
         ReduceArgs a;
         memset(&a, 0, sizeof a);
@@ -1236,6 +1345,7 @@ extern "C" int otto_covis_finalize(otto_covis_ctx* c, int group, int k, uint32_t
         a.boost = c->boost.as<uint8_t>();
         a.ovf_count = c->counters.as<uint32_t>();
         a.l_cap = c->l_cap;
+        a.debug_skip = c->debug_skip;
 
         bool first = true;
         for (;;) {
@@ -1278,6 +1388,7 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
         c->index_valid = false;
         return 0;
     }
+    if (strcmp(name, "debug_skip") == 0) { c->debug_skip = (int)value; return 0; }   // timing diagnostics, results invalid
     if (strcmp(name, "partition") == 0) {
         // 1 (default): bucket heavy aids' records by hash partition once; 0: every partition re-reads
         // all of its aid's records and filters (round-1 baseline, kept for A/B measurements)

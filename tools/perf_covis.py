@@ -11,6 +11,8 @@ ap.add_argument('--kinds', default='click_weighted,cart_weighted,order_weighted'
 ap.add_argument('--reps', type=int, default=3)
 ap.add_argument('--l-cap', type=int, default=0)
 ap.add_argument('--k', type=int, default=20)
+ap.add_argument('--skip', type=int, default=0)
+ap.add_argument('--partition', type=int, default=1)
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 t = time.time()
@@ -21,6 +23,9 @@ kinds = tuple(a.kinds.split(','))
 b = CovisBuilder(OTTO_N_AIDS, kinds=kinds, ts_min=int(d['ts'].min()), ts_max=int(d['ts'].max()), device=dev)
 if a.l_cap:
     b.set_option('l_cap', a.l_cap)
+if a.skip:
+    b.set_option('debug_skip', a.skip)
+b.set_option('partition', a.partition)
 for r in range(a.reps):
     b.reset()
     torch.cuda.synchronize(); t0 = time.time()
