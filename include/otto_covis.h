@@ -112,7 +112,7 @@ int otto_covis_stats(otto_covis_ctx* ctx, int64_t* out /* [OTTO_COVIS_STAT_COUNT
 
 /* Tuning knobs; results are exact for every value.
  *   "l_cap": expanded pairs per hash partition of a heavy aid_x (default 6144);
- *   "partition": 1 (default) bucket heavy aids' pairs by partition once, 0 re-read and filter per partition. */
+ *   "partition": 1 (default) bucket heavy aids' pairs by partition once, 0 re-read and filter per partition */
 int otto_covis_set_option(otto_covis_ctx* ctx, const char* name, int64_t value);
 
 /*

@@ -516,15 +516,21 @@ __device__ __forceinline__ void for_each_record(const uint64_t* sorted_desc, con
     const unsigned lane = lane_id();
     const uint32_t l = lane & 31u;
     const int half = (int)(lane >> 5);
-    for (uint64_t cb = r0; cb < r1; cb += (uint64_t)NW * 64) {
+    if (r0 >= r1) return;
+    auto load_desc = [&](uint64_t cb) {
         const uint64_t mine = cb + (uint64_t)lane * NW + wid;
-        const uint64_t d = mine < r1 ? sorted_desc[mine] : 0ull;
-        const uint64_t left = r1 - cb;                                   // runs in this chunk (all waves)
+        return mine < r1 ? sorted_desc[mine] : 0ull;
+    };
+    uint64_t d = load_desc(r0);
+    for (uint64_t cb = r0; cb < r1; cb += (uint64_t)NW * 64) {
+        const uint64_t cbn = cb + (uint64_t)NW * 64;
+        const uint64_t dn = cbn < r1 ? load_desc(cbn) : 0ull;              // next descriptors in flight
+        const uint64_t left = r1 - cb;                                     // runs in this chunk (all waves)
         const int nrun = left >= (uint64_t)NW * 64 ? 64 : (int)((left + NW - 1 - wid) / NW);   // this wave's share
-        for (int t = 0; t < nrun; t += 2 * GATHER_U) {
-            uint32_t rc[GATHER_U];
-            uint64_t sl[GATHER_U];
-            bool ok[GATHER_U];
+        uint32_t rcA[GATHER_U], rcB[GATHER_U];
+        uint64_t slA[GATHER_U], slB[GATHER_U];
+        bool okA[GATHER_U], okB[GATHER_U];
+        auto issue = [&](int t, uint32_t (&rc)[GATHER_U], uint64_t (&sl)[GATHER_U], bool (&ok)[GATHER_U]) {
 #pragma unroll
             for (int u = 0; u < GATHER_U; ++u) {
                 const int src = t + 2 * u + half;
@@ -533,10 +539,22 @@ __device__ __forceinline__ void for_each_record(const uint64_t* sorted_desc, con
                 ok[u] = src < 64 && l < (uint32_t)(dd & 0xFFull);
                 rc[u] = ok[u] ? rec[sl[u]] : 0u;
             }
+        };
+        auto consume = [&](uint32_t (&rc)[GATHER_U], uint64_t (&sl)[GATHER_U], bool (&ok)[GATHER_U]) {
 #pragma unroll
             for (int u = 0; u < GATHER_U; ++u)
                 if (ok[u]) f(rc[u], sl[u]);
+        };
+        // two batches of 2*GATHER_U runs alternate: the loads of one are in flight while the other is consumed
+        if (nrun > 0) issue(0, rcA, slA, okA);
+        for (int t = 0; t < nrun; t += 4 * GATHER_U) {
+            const bool hasB = t + 2 * GATHER_U < nrun;
+            if (hasB) issue(t + 2 * GATHER_U, rcB, slB, okB);
+            consume(rcA, slA, okA);
+            if (t + 4 * GATHER_U < nrun) issue(t + 4 * GATHER_U, rcA, slA, okA);
+            if (hasB) consume(rcB, slB, okB);
         }
+        d = dn;
     }
 }
 
@@ -566,7 +584,7 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
     constexpr int NW = 4;
     constexpr int RL = 1 << PART_LDS_LOG2R;
     __shared__ uint32_t s_cnt[RL];
-    __shared__ uint64_t s_base[SCATTER ? RL : 1];
+    __shared__ uint32_t s_base[SCATTER ? RL : 1];   // bucket cursor start relative to the aid's first bucket
     const int wid = threadIdx.x >> 6;
     for (uint32_t ci = blockIdx.x; ci < a.n_chunks; ci += gridDim.x) {
         const uint64_t ch = a.chunks[ci];
@@ -576,10 +594,11 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
         const uint32_t R = 1u << lgR, pmask = R - 1u;
         const int pshift = 32 - L_LOG2T - lgR;
         const uint64_t g0 = a.litem_start[x];
+        const uint64_t x_base = SCATTER ? a.pstart[g0] : 0ull;
         const uint64_t rb = a.run_start[x] + c * PART_CHUNK_RUNS;
         uint64_t re = rb + PART_CHUNK_RUNS;
         if (re > a.run_start[x + 1]) re = a.run_start[x + 1];
-        if (lgR > PART_LDS_LOG2R) {
+        if (lgR > PART_LDS_LOG2R || (a.cnt64[x] & CNT_REC_MASK) >= (1ull << 32)) {
             // more partitions than LDS counters: global atomics per record (giant aids only)
             for_each_record<NW>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t slot) {
                 const uint64_t g = g0 + ((rec_hash(rc) >> pshift) & pmask);
@@ -606,13 +625,13 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
         } else {
             for (uint32_t p = threadIdx.x; p < R; p += 256) {
                 const uint32_t n = s_cnt[p];
-                if (n) s_base[p] = a.pstart[g0 + p] + atomicAdd(&a.pcursor[g0 + p], n);
+                if (n) s_base[p] = (uint32_t)(a.pstart[g0 + p] - x_base) + atomicAdd(&a.pcursor[g0 + p], n);
                 s_cnt[p] = 0;
             }
             __syncthreads();
             for_each_record<NW>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t slot) {
                 const uint32_t p = (rec_hash(rc) >> pshift) & pmask;
-                const uint64_t pos = s_base[p] + atomicAdd(&s_cnt[p], 1u);
+                const uint64_t pos = x_base + s_base[p] + atomicAdd(&s_cnt[p], 1u);
                 a.prec[pos] = rc;
                 if (a.ptw) a.ptw[pos] = a.tw[slot];
             });
@@ -1268,8 +1287,9 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
                         c->run_start.as<uint64_t>(), c->sorted_desc.as<uint64_t>(), c->rec.as<uint32_t>(), c->tw.as<uint32_t>(),
                         c->litem_start.as<uint64_t>(), c->pcount.as<uint32_t>(), c->pcursor.as<uint32_t>(),
                         c->pstart.as<uint64_t>(), c->prec.as<uint32_t>(), time ? c->ptw.as<uint32_t>() : nullptr, c->l_cap};
-            const uint32_t pgrid = (uint32_t)(c->n_chunks < 256u * 3u ? c->n_chunks : 256u * 3u);
-            k_partition<false><<<pgrid, 256, 0, s>>>(pa);
+            const uint32_t pgrid = (uint32_t)(c->n_chunks < 256u * 5u ? c->n_chunks : 256u * 5u);
+            const uint32_t cgrid = (uint32_t)(c->n_chunks < 256u * 8u ? c->n_chunks : 256u * 8u);
+            k_partition<false><<<cgrid, 256, 0, s>>>(pa);
             OTTO_HIP(hipGetLastError());
             OTTO_TRY(device_scan(PCount{c->pcount.as<uint32_t>()}, (int64_t)a.n_items, c->pstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
             k_partition<true><<<pgrid, 256, 0, s>>>(pa);
