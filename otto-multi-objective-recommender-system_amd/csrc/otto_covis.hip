@@ -134,7 +134,28 @@ struct WinEvents {  // n run slots of session i
 constexpr uint32_t M_EMPTY = 0xFFFFFFFFu;
 constexpr int REC_AID_BITS = 26;
 constexpr uint32_t REC_AID_MASK = (1u << REC_AID_BITS) - 1;
-constexpr int EXP_HW = 8;   // half-waves (= session windows) per 256-thread workgroup
+
+// window size classes: a window of n events runs on G = 8 / 16 / 32 lanes (8 / 4 / 2 windows per wave)
+__device__ __forceinline__ int win_class(int64_t len, int W) {
+    const int64_t n = len < W ? len : W;
+    return n < 2 ? -1 : (n <= 8 ? 0 : (n <= 16 ? 1 : 2));
+}
+struct WinClass {   // 1 if session i falls in size class `cls`
+    const int64_t* off;
+    int W;
+    int cls;
+    __device__ uint64_t operator()(int64_t i) const { return win_class(off[i + 1] - off[i], W) == cls ? 1ull : 0ull; }
+};
+// sess_list[class_base[c] + rank within class] = session index
+__global__ void k_fill_classes(const int64_t* off, int W, int64_t n_sess, const uint64_t* pos0, const uint64_t* pos1,
+                               const uint64_t* pos2, uint64_t base1, uint64_t base2, uint32_t* sess_list) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_sess) return;
+    const int c = win_class(off[s + 1] - off[s], W);
+    if (c == 0) sess_list[pos0[s]] = (uint32_t)s;
+    else if (c == 1) sess_list[base1 + pos1[s]] = (uint32_t)s;
+    else if (c == 2) sess_list[base2 + pos2[s]] = (uint32_t)s;
+}
 
 struct ExpandArgs {
     const uint32_t* aid;
@@ -143,7 +164,8 @@ struct ExpandArgs {
     const int64_t* sess_off;
     const uint64_t* pair_base;   // [S+1] chunk-local exclusive scans
     const uint64_t* ev_base;
-    int64_t n_sess;
+    const uint32_t* sess_list;   // sessions of this size class
+    int64_t n_list;
     uint32_t* rec;
     uint32_t* tw;
     uint32_t* run_x;
@@ -157,92 +179,123 @@ struct ExpandArgs {
     uint32_t fmask[4];
 };
 
-template <bool TIME>
+// LDS traffic between the lanes of ONE wave: the LDS queue of a wave is in order, so only the compiler
+// needs a fence -- no workgroup barrier anywhere in this kernel.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// G lanes per window, 64/G windows per wave, 4 independent waves per workgroup.
+//  A: load the window; class id of an event = first position holding the same aid.
+//  B: every ordered pair (i, lane): valid pairs race with ds_min for M[class_x][class_y] = first (i << 5 | j);
+//     filter kinds OR their mask bit into FB[class_x][class_y].
+//  C: per class row: ballot/popcount compaction of the non-empty columns -> contiguous 4-byte records
+//     (a run), one (aid_x, slot << 8 | len) descriptor per window event.
+template <int G, bool TIME, bool FILT>
 __global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
-    __shared__ uint4 s_ev[EXP_HW][32];            // aid, ts, type | cls << 8, time extra
-    __shared__ uint32_t s_M[EXP_HW][32 * 32];     // first valid (i << 5 | j) per (class_x, class_y)
-    __shared__ uint32_t s_FB[EXP_HW][32 * 4];     // 4 filter bits per (class_x, class_y)
+    constexpr int WPW = 64 / G;                    // windows per wave
+    constexpr int FBW = (G + 7) / 8;               // FB words per row (4 bits per column)
+    __shared__ uint4 s_ev[4][WPW][G];              // aid, ts, type | cls << 8, time extra
+    __shared__ uint32_t s_M[4][WPW][G * G];
+    __shared__ uint32_t s_FB[4][WPW][FILT ? G * FBW : 1];
 
-    const int hw = threadIdx.x >> 5;
-    const int l = threadIdx.x & 31;
-    const unsigned half_shift = threadIdx.x & 32;
-    const int64_t stride = (int64_t)gridDim.x * EXP_HW;
+    const int wv = threadIdx.x >> 6;
+    const unsigned lane = lane_id();
+    const int grp = lane / G, g = lane % G;
+    const unsigned grp_shift = grp * G;
+    const uint64_t gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+    uint4* ev = s_ev[wv][grp];
+    uint32_t* M = s_M[wv][grp];
+    uint32_t* FB = s_FB[wv][FILT ? grp : 0];
 
-    for (int64_t s0 = (int64_t)blockIdx.x * EXP_HW; s0 < a.n_sess; s0 += stride) {
-        const int64_t s = s0 + hw;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t wave_stride = (int64_t)gridDim.x * 4;
+    for (int64_t w0 = wave_global * WPW; w0 < a.n_list; w0 += wave_stride * WPW) {
+        const int64_t li = w0 + grp;
         int n = 0;
         int64_t wstart = 0;
         uint64_t pbase = 0, ebase = 0;
-        if (s < a.n_sess) {
-            int64_t lo = a.sess_off[s], hi = a.sess_off[s + 1];
-            int64_t len = hi - lo;
+        if (li < a.n_list) {
+            const int64_t s = a.sess_list[li];
+            const int64_t lo = a.sess_off[s], hi = a.sess_off[s + 1];
+            const int64_t len = hi - lo;
             n = (int)(len < a.window ? len : a.window);
-            if (n < 2) n = 0;
             wstart = hi - n;
             pbase = a.pair_base[s];
             ebase = a.ev_base[s];
         }
-        // ---- phase A: load the window, class ids -------------------------------------------
+        // ---- A ----
         uint32_t aid = 0xFFFFFFFFu, ty = 0, extra = 0;
         int32_t t = 0;
-        if (l < n) {
-            aid = a.aid[wstart + l];
-            t = a.ts[wstart + l];
-            ty = a.type[wstart + l];
+        if (g < n) {
+            aid = a.aid[wstart + g];
+            t = a.ts[wstart + g];
+            ty = a.type[wstart + g];
             if (TIME) extra = a.tspan > 0 ? (uint32_t)((uint64_t)(196608ull * (uint64_t)((int64_t)t - a.t0)) / (uint64_t)a.tspan) : 0u;
         }
-        s_ev[hw][l] = make_uint4(aid, (uint32_t)t, ty, extra);
-        __syncthreads();
-        int cls = l;
-        for (int j = n - 1; j >= 0; --j)
-            if (s_ev[hw][j].x == aid) cls = j;
-        if (l < n) {
-            s_ev[hw][l].z = ty | ((uint32_t)cls << 8);
-            s_FB[hw][l * 4 + 0] = 0; s_FB[hw][l * 4 + 1] = 0; s_FB[hw][l * 4 + 2] = 0; s_FB[hw][l * 4 + 3] = 0;
+        ev[g] = make_uint4(aid, (uint32_t)t, ty, extra);
+        wave_lds_sync();
+        int cls = g;
+        for (int j = G - 1; j >= 0; --j) {
+            if (__ballot(j < n) == 0) continue;
+            if (j < n && ev[j].x == aid) cls = j;
         }
-        for (int r = 0; r < n; ++r) s_M[hw][r * 32 + l] = M_EMPTY;
-        __syncthreads();
-        // ---- phase B: every ordered pair (i, l); first valid pair per class pair -----------
-        if (l < n) {
-            for (int i = 0; i < n; ++i) {
-                const uint4 e = s_ev[hw][i];
+        if (g < n) {
+            ev[g].z = ty | ((uint32_t)cls << 8);
+            if (FILT)
+                for (int q = 0; q < FBW; ++q) FB[g * FBW + q] = 0;
+        }
+        for (int r = 0; r < G; ++r) {
+            if (__ballot(r < n) == 0) break;
+            if (r < n) M[r * G + g] = M_EMPTY;
+        }
+        wave_lds_sync();
+        // ---- B ----
+        for (int i = 0; i < G; ++i) {
+            if (__ballot(i < n) == 0) break;
+            if (i < n && g < n) {
+                const uint4 e = ev[i];
                 int dt = (int)e.y - t;
                 dt = dt < 0 ? -dt : dt;
                 if (e.x != aid && dt <= a.max_gap) {
-                    const uint32_t ci = e.z >> 8, yi = e.z & 0xFFu;
-                    atomicMin(&s_M[hw][ci * 32 + cls], (uint32_t)((i << 5) | l));
-                    const uint32_t bit = yi * 3 + ty;
-                    const uint32_t fb = ((a.fmask[0] >> bit) & 1u) | (((a.fmask[1] >> bit) & 1u) << 1) |
-                                        (((a.fmask[2] >> bit) & 1u) << 2) | (((a.fmask[3] >> bit) & 1u) << 3);
-                    if (fb) atomicOr(&s_FB[hw][ci * 4 + (cls >> 3)], fb << ((cls & 7) * 4));
+                    const uint32_t ci = e.z >> 8;
+                    atomicMin(&M[ci * G + cls], (uint32_t)((i << 5) | g));
+                    if (FILT) {
+                        const uint32_t bit = (e.z & 0xFFu) * 3 + ty;
+                        const uint32_t fb = ((a.fmask[0] >> bit) & 1u) | (((a.fmask[1] >> bit) & 1u) << 1) |
+                                            (((a.fmask[2] >> bit) & 1u) << 2) | (((a.fmask[3] >> bit) & 1u) << 3);
+                        if (fb) atomicOr(&FB[ci * FBW + (cls >> 3)], fb << ((cls & 7) * 4));
+                    }
                 }
             }
         }
-        __syncthreads();
-        // ---- phase C: emit rows (runs) in class order ---------------------------------------
+        wave_lds_sync();
+        // ---- C ----
         uint32_t off = 0, my_off = 0, my_cnt = 0;
-        for (int r = 0; r < n; ++r) {
-            const uint32_t e = (l < n) ? s_M[hw][r * 32 + l] : M_EMPTY;
+        for (int r = 0; r < G; ++r) {
+            if (__ballot(r < n) == 0) break;
+            const uint32_t e = (r < n && g < n) ? M[r * G + g] : M_EMPTY;
             const bool has = e != M_EMPTY;
-            const uint32_t hm = (uint32_t)(__ballot(has) >> half_shift);
+            const uint32_t hm = (uint32_t)((__ballot(has) >> grp_shift) & gmask);
             const uint32_t cnt = __popc(hm);
             if (has) {
-                const uint32_t rank = __popc(hm & ((1u << l) - 1u));
+                const uint32_t rank = __popc(hm & ((1u << g) - 1u));
                 const uint32_t i = e >> 5, j = e & 31u;
-                const uint32_t tyj = s_ev[hw][j].z & 0xFFu;
-                const uint32_t fb = (s_FB[hw][r * 4 + (l >> 3)] >> ((l & 7) * 4)) & 0xFu;
+                const uint32_t tyj = ev[j].z & 0xFFu;
+                const uint32_t fb = FILT ? (FB[r * FBW + (g >> 3)] >> ((g & 7) * 4)) & 0xFu : 0u;
                 const uint64_t slot = a.rec_base + pbase + off + rank;
                 a.rec[slot] = aid | (tyj << REC_AID_BITS) | (fb << 28);
-                if (TIME) a.tw[slot] = s_ev[hw][i].w;
+                if (TIME) a.tw[slot] = ev[i].w;
             }
-            if (l == r) { my_off = off; my_cnt = cnt; }
+            if (g == r) { my_off = off; my_cnt = cnt; }
             off += cnt;
         }
-        if (l < n) {
-            a.run_x[a.run_base + ebase + l] = aid;
-            a.run_desc[a.run_base + ebase + l] = my_cnt ? (((a.rec_base + pbase + my_off) << 8) | my_cnt) : 0ull;
+        if (g < n) {
+            a.run_x[a.run_base + ebase + g] = aid;
+            a.run_desc[a.run_base + ebase + g] = my_cnt ? (((a.rec_base + pbase + my_off) << 8) | my_cnt) : 0ull;
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 
@@ -1031,7 +1084,7 @@ struct otto_covis_ctx {
     uint64_t run_used = 0;    // run slots
     int64_t sessions = 0;
     // chunk scratch
-    DevBuf pair_base, ev_base, partial;
+    DevBuf pair_base, ev_base, partial, cls_pos[3], sess_list;
     // index
     bool index_valid = false;
     DevBuf cnt64, run_start, cursor, sorted_desc, item_start, boost, flag, counters;
@@ -1090,6 +1143,7 @@ extern "C" int otto_covis_create(otto_covis_ctx** out, const otto_covis_params* 
 extern "C" void otto_covis_destroy(otto_covis_ctx* c) {
     if (!c) return;
     DevBuf* all[] = {&c->rec, &c->tw, &c->run_x, &c->run_desc, &c->pair_base, &c->ev_base, &c->partial, &c->cnt64,
+                     &c->cls_pos[0], &c->cls_pos[1], &c->cls_pos[2], &c->sess_list,
                      &c->run_start, &c->cursor, &c->sorted_desc, &c->item_start, &c->boost, &c->flag, &c->counters,
                      &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->exp_run_pos, &c->exp_rec_pos,
                      &c->litem_start, &c->chunks, &c->pcount, &c->pcursor, &c->pstart, &c->prec, &c->ptw};
@@ -1125,36 +1179,65 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
     OTTO_TRY(c->partial.ensure(scan_partial_bytes(n_sess > (int64_t)p.n_aids ? n_sess : (int64_t)p.n_aids), 0, s));
     OTTO_TRY(device_scan(WinPairs{d_sess_off, p.window}, n_sess, c->pair_base.as<uint64_t>(), c->partial.as<uint64_t>(), s));
     OTTO_TRY(device_scan(WinEvents{d_sess_off, p.window}, n_sess, c->ev_base.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+    // size classes of the windows (<= 8 / <= 16 / <= 32 events): one session list, three segments
+    OTTO_REQUIRE(n_sess < (1ll << 32), "more than 2^32 sessions in one chunk");
+    for (int cl = 0; cl < 3; ++cl) {
+        OTTO_TRY(c->cls_pos[cl].ensure((size_t)(n_sess + 1) * 8, 0, s));
+        OTTO_TRY(device_scan(WinClass{d_sess_off, p.window, cl}, n_sess, c->cls_pos[cl].as<uint64_t>(), c->partial.as<uint64_t>(), s));
+    }
     tend(c, OTTO_COVIS_T_WINSCAN, s);
-    uint64_t totals[2];
+    uint64_t totals[5];
     OTTO_HIP(hipMemcpyAsync(&totals[0], c->pair_base.as<uint64_t>() + n_sess, 8, hipMemcpyDeviceToHost, s));
     OTTO_HIP(hipMemcpyAsync(&totals[1], c->ev_base.as<uint64_t>() + n_sess, 8, hipMemcpyDeviceToHost, s));
+    for (int cl = 0; cl < 3; ++cl)
+        OTTO_HIP(hipMemcpyAsync(&totals[2 + cl], c->cls_pos[cl].as<uint64_t>() + n_sess, 8, hipMemcpyDeviceToHost, s));
     OTTO_HIP(hipStreamSynchronize(s));
     const uint64_t n_slots = totals[0], n_ev = totals[1];
+    const uint64_t n_cls[3] = {totals[2], totals[3], totals[4]};
     OTTO_REQUIRE(c->rec_used + n_slots < (1ull << 55), "record slot space exhausted");
 
     OTTO_TRY(c->rec.ensure((size_t)(c->rec_used + n_slots) * 4, (size_t)c->rec_used * 4, s));
     if (p.want_time) OTTO_TRY(c->tw.ensure((size_t)(c->rec_used + n_slots) * 4, (size_t)c->rec_used * 4, s));
     OTTO_TRY(c->run_x.ensure((size_t)(c->run_used + n_ev) * 4, (size_t)c->run_used * 4, s));
     OTTO_TRY(c->run_desc.ensure((size_t)(c->run_used + n_ev) * 8, (size_t)c->run_used * 8, s));
+    OTTO_TRY(c->sess_list.ensure((size_t)(n_sess + 1) * 4, 0, s));
 
+    tbegin(c, OTTO_COVIS_T_EXPAND, s);
+    k_fill_classes<<<(unsigned)((n_sess + 255) / 256), 256, 0, s>>>(d_sess_off, p.window, n_sess, c->cls_pos[0].as<uint64_t>(),
+                                                                     c->cls_pos[1].as<uint64_t>(), c->cls_pos[2].as<uint64_t>(),
+                                                                     n_cls[0], n_cls[0] + n_cls[1], c->sess_list.as<uint32_t>());
+    OTTO_HIP(hipGetLastError());
     ExpandArgs a;
     a.aid = d_aid; a.ts = d_ts; a.type = d_type; a.sess_off = d_sess_off;
     a.pair_base = c->pair_base.as<uint64_t>(); a.ev_base = c->ev_base.as<uint64_t>();
-    a.n_sess = n_sess;
     a.rec = c->rec.as<uint32_t>(); a.tw = c->tw.as<uint32_t>();
     a.run_x = c->run_x.as<uint32_t>(); a.run_desc = c->run_desc.as<uint64_t>();
     a.rec_base = c->rec_used; a.run_base = c->run_used;
     a.window = p.window; a.max_gap = p.max_gap;
     a.t0 = p.ts_min; a.tspan = (int64_t)p.ts_max - (int64_t)p.ts_min;
     for (int f = 0; f < 4; ++f) a.fmask[f] = f < p.n_filters ? p.filter_mask[f] : 0u;
-
-    int64_t groups = (n_sess + EXP_HW - 1) / EXP_HW;
-    int grid = (int)(groups < 256 * 16 ? groups : 256 * 16);
-    tbegin(c, OTTO_COVIS_T_EXPAND, s);
-    if (p.want_time) k_expand<true><<<grid, 256, 0, s>>>(a);
-    else k_expand<false><<<grid, 256, 0, s>>>(a);
-    OTTO_HIP(hipGetLastError());
+    uint64_t lbase = 0;
+    for (int cl = 0; cl < 3; ++cl) {
+        a.sess_list = c->sess_list.as<uint32_t>() + lbase;
+        a.n_list = (int64_t)n_cls[cl];
+        lbase += n_cls[cl];
+        if (a.n_list == 0) continue;
+        const int wpw = cl == 0 ? 8 : (cl == 1 ? 4 : 2);
+        const int64_t waves = (a.n_list + wpw - 1) / wpw;
+        const int64_t blocks = (waves + 3) / 4;
+        const int grid = (int)(blocks < 256 * 16 ? blocks : 256 * 16);
+        const int variant = (p.want_time ? 2 : 0) | (p.n_filters > 0 ? 1 : 0);
+#define OTTO_EXPAND(G)                                                                   \
+        switch (variant) {                                                               \
+            case 0: k_expand<G, false, false><<<grid, 256, 0, s>>>(a); break;            \
+            case 1: k_expand<G, false, true><<<grid, 256, 0, s>>>(a); break;             \
+            case 2: k_expand<G, true, false><<<grid, 256, 0, s>>>(a); break;             \
+            default: k_expand<G, true, true><<<grid, 256, 0, s>>>(a); break;             \
+        }
+        if (cl == 0) { OTTO_EXPAND(8) } else if (cl == 1) { OTTO_EXPAND(16) } else { OTTO_EXPAND(32) }
+#undef OTTO_EXPAND
+        OTTO_HIP(hipGetLastError());
+    }
     tend(c, OTTO_COVIS_T_EXPAND, s);
 
     c->rec_used += n_slots;
