@@ -55,6 +55,11 @@ def algorithmic_bytes(st, k, nk):
         # write one 4-byte record per pair and one (aid_x u32, descriptor u64) per window event
         'expand': 9 * Et + 24 * S + 4 * P + 12 * Et,
     }
+    # index: read (aid_x u32, descriptor u64) per window event twice (histogram, scatter), write one descriptor per run
+    out['index'] = 2 * 12 * Et + 8 * st['runs']
+    # partition: the heavy aids' records are read once and written once into buckets (the count pass and the
+    # second read of the scatter pass are overhead, not algorithmic), plus their run descriptors
+    out['partition'] = 8 * st['pairs_l'] + 8 * st['runs_l']
     for b, name in (('s', 'reduce_s'), ('m', 'reduce_m'), ('l', 'reduce_l')):
         aids = st[f'items_{b}'] if b != 'l' else 0
         # read every record (4 B) and run descriptor (8 B) of the bin once, 24 B of item/run_start
@@ -116,16 +121,24 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != a.gpus:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}')
-    dev = torch.device(f'cuda:{local_rank}')
+    # rehearsal hooks (not used by the driver): OTTO_BENCH_BACKEND=gloo stages the exchange through host
+    # memory and OTTO_BENCH_DEVICE pins every rank to one GPU, so the N > 1 code path can be exercised on a
+    # one-GPU box. The real run is nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get('OTTO_BENCH_BACKEND', 'nccl')
+    stage = 'cpu' if backend == 'gloo' else None
+    dev = torch.device(f"cuda:{os.environ.get('OTTO_BENCH_DEVICE', local_rank)}")
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     data = generate_sessions_torch(a.sessions, n_aids=OTTO_N_AIDS, seed=42 + rank, device=dev)
     n_aids = data['n_aids']
     if world > 1:
-        ts_min, ts_max = global_ts_range(data['ts'])
-        builder = ShardedCovisBuilder(n_aids, BENCH_KINDS, ts_min, ts_max, dev)
+        ts_min, ts_max = global_ts_range(data['ts'].cpu() if stage else data['ts'])
+        builder = ShardedCovisBuilder(n_aids, BENCH_KINDS, ts_min, ts_max, dev, stage_device=stage)
         eng = builder.owner
     else:
         ts_min, ts_max = int(data['ts'].min()), int(data['ts'].max())
@@ -162,7 +175,7 @@ def main():
     st_expand = builder.local.stats() if world > 1 else st
     pairs = st['pairs']
     if world > 1:
-        red = torch.tensor([dt, float(pairs)], dtype=torch.float64, device=dev)
+        red = torch.tensor([dt, float(pairs)], dtype=torch.float64, device='cpu' if stage else dev)
         mx = red.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = red.clone()
@@ -178,10 +191,11 @@ def main():
         else:
             st_k = st
         ab = algorithmic_bytes(st_k, a.k, nk)
-        cand = {n: kernel_ms.get(n, 0.0) for n in ('expand', 'reduce_s', 'reduce_m', 'reduce_l')}
+        cand = {n: kernel_ms.get(n, 0.0) for n in ('expand', 'index', 'partition', 'reduce_s', 'reduce_m', 'reduce_l')}
         dom = max(cand, key=cand.get)
-        knames = {'expand': 'k_expand<false>', 'reduce_s': 'k_reduce<9,64,TYPE>', 'reduce_m': 'k_reduce<12,256,TYPE>',
-                  'reduce_l': 'k_reduce<13,1024,TYPE>'}
+        knames = {'expand': 'k_expand<G,false,false> (G = 8, 16, 32 size-class launches + k_fill_classes)',
+                  'reduce_s': 'k_reduce<9,64,0>', 'reduce_m': 'k_reduce<12,256,0>', 'reduce_l': 'k_reduce<13,1024,0>',
+                  'partition': 'k_partition<false> + k_partition<true>', 'index': 'k_hist_runs + k_scatter_runs + scans'}
         result = {
             'metric': 'aid-pairs/sec covisitation build',
             'value': round(pairs * a.steps / dt, 1),

@@ -18,8 +18,11 @@ def owner_bounds(n_aids, world):
     return [int(round(i * n_aids / world)) for i in range(world + 1)]
 
 
-def exchange_runs(export_fn, import_fn, bounds, group=None, want_time=False):
+def exchange_runs(export_fn, import_fn, bounds, group=None, want_time=False, stage_device=None):
     """Route runs to their aid_x owners.
+
+    ``stage_device`` (e.g. ``'cpu'`` with a gloo group): move the pieces there for the collectives and
+    back afterwards -- used to rehearse the multi-rank path on a single GPU; with nccl leave it None.
 
     ``export_fn(lo, hi) -> (hdr int32 [n,2], rec int32 [m], tw int32 [m] | None)`` on the local
     engine, ``import_fn(hdr, rec, tw)`` on the owner engine.  Works on any tensor device the
@@ -30,6 +33,9 @@ def exchange_runs(export_fn, import_fn, bounds, group=None, want_time=False):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     pieces = [export_fn(bounds[r], bounds[r + 1]) for r in range(world)]
+    home = pieces[0][0].device
+    if stage_device is not None:
+        pieces = [tuple(None if t is None else t.to(stage_device) for t in p) for p in pieces]
     dev = pieces[0][0].device
     send_counts = torch.tensor([[p[0].shape[0], p[1].numel()] for p in pieces], dtype=torch.int64, device=dev)
     recv_counts = torch.empty_like(send_counts)
@@ -46,7 +52,9 @@ def exchange_runs(export_fn, import_fn, bounds, group=None, want_time=False):
     hdr = a2a([p[0] for p in pieces], 2, sc[:, 0], rc[:, 0]).reshape(-1, 2)
     rec = a2a([p[1] for p in pieces], 1, sc[:, 1], rc[:, 1])
     tw = a2a([p[2] for p in pieces], 1, sc[:, 1], rc[:, 1]) if want_time else None
-    import_fn(hdr, rec, tw)
+    if stage_device is not None:
+        hdr, rec, tw = hdr.to(home), rec.to(home), None if tw is None else tw.to(home)
+    import_fn(hdr.contiguous(), rec.contiguous(), tw)
     return int(sc[:, 0].sum()), int(sc[:, 1].sum()), int(rc[:, 0].sum()), int(rc[:, 1].sum())
 
 
@@ -65,10 +73,11 @@ class ShardedCovisBuilder:
     """Session-chunk sharded build on ``world`` GPUs; rank r owns aid_x in
     ``[bounds[r], bounds[r+1])`` and returns top-k rows for that range only."""
 
-    def __init__(self, n_aids, kinds, ts_min, ts_max, device, group=None, window=30, max_gap=86400):
+    def __init__(self, n_aids, kinds, ts_min, ts_max, device, group=None, window=30, max_gap=86400, stage_device=None):
         import torch.distributed as dist
         from .engine import CovisBuilder
         self.group = group
+        self.stage_device = stage_device
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.bounds = owner_bounds(n_aids, self.world)
@@ -85,5 +94,5 @@ class ShardedCovisBuilder:
 
     def finalize(self, k=20, out=None):
         self.last_exchange = exchange_runs(self.local.export_runs, self.owner.import_runs, self.bounds, self.group,
-                                           self.local.want_time)
+                                           self.local.want_time, self.stage_device)
         return self.owner.finalize(k=k, out=out)

@@ -104,7 +104,7 @@ def run(a, dev, rank, world):
     dt = time.perf_counter() - t0
     last_loss = float(loss.sum().item()) / rows
     if world > 1:
-        mx = torch.tensor([dt], dtype=torch.float64, device=dev)
+        mx = torch.tensor([dt], dtype=torch.float64, device='cpu' if dist.get_backend() == 'gloo' else dev)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dt = float(mx.item())
     total = rows * a.steps * world

@@ -205,3 +205,71 @@ def test_golden_fixture_and_hand_computed_sessions(gpu_device):
         gx, gy, gw = got[kind]
         d = dict(zip(zip(gx.tolist(), gy.tolist()), gw.tolist()))
         assert d == ({p: w * cs.Q16 for p, w in want.items()} if want is not None else HAND_TIME), kind
+
+
+def _sharded_worker(rank, world, port, q, root):
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path[:0] = [root, os.path.join(root, 'oracle')]
+    import torch
+    import torch.distributed as dist
+    from otto_amd.covisitation.distributed import ShardedCovisBuilder, global_ts_range
+    from otto_amd.covisitation.engine import topk_to_rows
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda:0')
+    ev = generate_sessions(3000, n_aids=900, seed=61)
+    per = ev.n_sessions // world
+    lo, hi = rank * per, ev.n_sessions if rank == world - 1 else (rank + 1) * per
+    e0, e1 = int(ev.sess_off[lo]), int(ev.sess_off[hi])
+    aid = torch.from_numpy(ev.aid[e0:e1].astype(np.int32)).to(dev)
+    ts = torch.from_numpy(ev.ts[e0:e1]).to(dev)
+    typ = torch.from_numpy(ev.type[e0:e1]).to(dev)
+    off = torch.from_numpy(ev.sess_off[lo:hi + 1] - e0).to(dev)
+    ts_min, ts_max = global_ts_range(ts.cpu())
+    b = ShardedCovisBuilder(ev.n_aids, cs.ALL_KINDS, ts_min, ts_max, dev, stage_device='cpu')
+    out_rows = None
+    for _ in range(2):                      # twice: reset() must leave no state behind (bench loops like this)
+        b.reset()
+        b.feed(aid, ts, typ, off)
+        out = b.finalize(k=20)
+        out_rows = {k: topk_to_rows(*out[k]) for k in cs.ALL_KINDS}
+    q.put((rank, b.bounds, out_rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_builder_two_ranks_on_one_gpu(gpu_device):
+    """The real ShardedCovisBuilder (the N > 1 path of bench.py) with 2 processes sharing this GPU; the
+    all-to-all-v runs over gloo with the pieces staged through host memory. Union of the two owners'
+    rows == single-context build."""
+    import socket
+    import torch.multiprocessing as mp
+    from conftest import ROOT
+    ev = generate_sessions(3000, n_aids=900, seed=61)
+    _, want = _build(ev, gpu_device)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, ROOT)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in ps:
+        r, bounds, rows = q.get(timeout=300)
+        res[r] = (bounds, rows)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    merged = {}
+    for kind in cs.ALL_KINDS:
+        parts = []
+        for r in range(2):
+            bounds, rows = res[r]
+            gx = rows[kind][0]
+            assert ((gx >= bounds[r]) & (gx < bounds[r + 1])).all()
+            parts.append(rows[kind])
+        merged[kind] = tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
+    _assert_rows_equal(merged, want, cs.ALL_KINDS)
