@@ -722,16 +722,32 @@ __global__ void k_fill_chunks(ChunkCount f, uint32_t n_aids, const uint64_t* chu
 }
 
 // ---- the reduce kernel --------------------------------------------------------------------------------
-template <int LOG2T, int THREADS, int GROUP>
+// PACKED (S / M bins, not the time group): a table slot is ONE 64-bit word  aid_y << 36 | c2 << 24 | c1 << 12 | c0
+// (an aid of these bins has <= M_CAP < 4096 records, so no 12-bit counter can overflow): one LDS read per probe,
+// one LDS atomic per record, and half the LDS of the wide layout (key word + three 32-bit counters) -> twice the
+// resident workgroups per CU. The L bin and the time group keep the wide layout.
+constexpr uint64_t TAB_EMPTY = ~0ull;
+
+struct ItemDesc {      // everything a workgroup needs about its item, fetched one item ahead by thread 0
+    uint32_t it;
+    uint64_t item;
+    uint64_t rb, re;   // run range of the aid
+    uint64_t ps, pe;   // bucket range (partitioned heavy aids)
+};
+
+template <int LOG2T, int THREADS, int GROUP, bool PACKED>
 __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
     constexpr int T = 1 << LOG2T;
     constexpr int NW = THREADS / 64;
     using K = typename std::conditional<GROUP == OTTO_COVIS_GROUP_TIME, KeyW, KeyN>::type;
-    __shared__ uint32_t s_key[T];
-    __shared__ uint32_t s_v[3][T];
     constexpr bool WIDE = GROUP == OTTO_COVIS_GROUP_TIME;
+    static_assert(!(PACKED && WIDE), "the time group needs the wide table layout");
+    constexpr bool DYNAMIC = THREADS != S_THREADS;   // work items dequeued with an atomic counter
     constexpr int EXCAP = 64;
     constexpr int PKD = WIDE ? 1 : PK;      // the time-weighted group has a single kind
+    __shared__ uint64_t s_tab[PACKED ? T : 1];
+    __shared__ uint32_t s_key[PACKED ? 1 : T];
+    __shared__ uint32_t s_v[3][PACKED ? 1 : T];
     __shared__ uint64_t s_lbw[NW > 1 ? PKD : 1][NW > 1 ? THREADS : 1];         // lane-best keys
     __shared__ uint32_t s_lby[1][(NW > 1 && WIDE) ? THREADS : 1];
     __shared__ uint64_t s_exw[NW > 1 ? PKD : 1][NW > 1 ? EXCAP : 1];           // candidates above the threshold
@@ -740,43 +756,72 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
     __shared__ uint32_t s_thry[PK];
     __shared__ uint32_t s_nex[PK];
     __shared__ uint32_t s_more;
-    __shared__ uint32_t s_item;
     __shared__ uint32_t s_ovf;
+    __shared__ ItemDesc s_cur;
 
     const int wid = threadIdx.x >> 6;
     const unsigned lane = lane_id();
-    uint32_t it = blockIdx.x;
-    uint32_t nxt = 0;
-    bool first_item = true;
+
+    // ---- item pipeline: (index, item word, run range, bucket range) of the NEXT item are fetched while the
+    //      current one is reduced, so the dependent loads index -> item -> run_start are off the critical path
+    auto fetch_item = [&](uint32_t idx, ItemDesc& d) {     // stage 1: item word
+        d.it = idx;
+        d.item = idx < a.n_items ? a.items[idx] : 0ull;
+    };
+    auto fetch_ranges = [&](ItemDesc& d) {                 // stage 2: ranges (needs the item word)
+        d.rb = d.re = d.ps = d.pe = 0;
+        if (d.it < a.n_items) {
+            const uint32_t xx = (uint32_t)(d.item & REC_AID_MASK);
+            d.rb = a.run_start[xx];
+            d.re = a.run_start[xx + 1];
+            if ((d.item >> 50) != 0 && a.pstart) { d.ps = a.pstart[d.it]; d.pe = a.pstart[d.it + 1]; }
+        }
+    };
+    ItemDesc cur, nx;
+    uint32_t idx_next = 0, idx_far = 0;   // DYNAMIC, thread 0: dequeued indices of the next two items
+    if (DYNAMIC) {
+        if (threadIdx.x == 0) {
+            const uint32_t i0 = atomicAdd(a.work_counter, 1u);
+            idx_next = atomicAdd(a.work_counter, 1u);
+            idx_far = atomicAdd(a.work_counter, 1u);
+            fetch_item(i0, cur);
+            fetch_ranges(cur);
+            s_cur = cur;
+        }
+    } else {
+        fetch_item(blockIdx.x, cur);
+        fetch_ranges(cur);
+    }
 
     for (;;) {
-        if (THREADS == S_THREADS) {
-            if (it >= a.n_items) break;
-        } else {
-            // dynamic dequeue, one item ahead: the atomic for the NEXT item was issued while the
-            // previous one was being reduced, so its latency is off the critical path
+        if (DYNAMIC) {
             __syncthreads();
-            if (threadIdx.x == 0) {
-                if (first_item) nxt = atomicAdd(a.work_counter, 1u);
-                s_item = nxt;
-            }
-            __syncthreads();
-            it = s_item;
-            if (it >= a.n_items) break;
-            if (threadIdx.x == 0) nxt = atomicAdd(a.work_counter, 1u);
-            first_item = false;
+            cur = s_cur;
         }
-        const uint64_t item = a.items[it];
+        if (cur.it >= a.n_items) break;
+        const uint32_t it = cur.it;
+        // stage 1 of the next item
+        if (DYNAMIC) {
+            if (threadIdx.x == 0) fetch_item(idx_next, nx);
+        } else {
+            fetch_item(it + gridDim.x, nx);
+        }
+        const uint64_t item = cur.item;
         const uint32_t x = (uint32_t)(item & REC_AID_MASK);
         const uint32_t part = (uint32_t)((item >> 26) & 0xFFFFFFu);
         const int lgR = (int)(item >> 50);
         const uint32_t pmask = (1u << lgR) - 1u;
         const int pshift = 32 - LOG2T - lgR;
 
-        if (!(a.debug_skip & 4))
-        for (int i = threadIdx.x; i < T; i += THREADS) {
-            s_key[i] = KEY_EMPTY;
-            s_v[0][i] = 0; s_v[1][i] = 0; s_v[2][i] = 0;
+        if (!(a.debug_skip & 4)) {
+            for (int i = threadIdx.x; i < T; i += THREADS) {
+                if (PACKED) {
+                    s_tab[i] = TAB_EMPTY;
+                } else {
+                    s_key[i] = KEY_EMPTY;
+                    s_v[0][i] = 0; s_v[1][i] = 0; s_v[2][i] = 0;
+                }
+            }
         }
         if (threadIdx.x == 0) s_ovf = 0;
         __syncthreads();
@@ -794,6 +839,26 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
                 if (!(add0 | add1 | add2)) return;
             }
             uint32_t slot = h >> (32 - LOG2T);
+            if (PACKED) {
+                const unsigned long long add = (unsigned long long)add0 | ((unsigned long long)add1 << 12) |
+                                               ((unsigned long long)add2 << 24);
+                const unsigned long long fresh = (unsigned long long)y << 36;
+                for (int probe = 0; probe < T; ++probe) {
+                    const uint64_t v = s_tab[slot];
+                    bool mine = v != TAB_EMPTY && (uint32_t)(v >> 36) == y;
+                    if (v == TAB_EMPTY) {
+                        const unsigned long long old = atomicCAS((unsigned long long*)&s_tab[slot], (unsigned long long)TAB_EMPTY, fresh);
+                        mine = old == TAB_EMPTY || (uint32_t)(old >> 36) == y;
+                    }
+                    if (mine) {
+                        atomicAdd((unsigned long long*)&s_tab[slot], add);
+                        return;
+                    }
+                    slot = (slot + 1) & (T - 1);
+                }
+                s_ovf = 1;
+                return;
+            }
             int found = -1;
             for (int probe = 0; probe < T; ++probe) {
                 const uint32_t kx = s_key[slot];
@@ -816,20 +881,26 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
             }
         };
 
-        // key of table slot i for kind j of this pass
-        auto slot_key = [&](int i, int j) {
-            K key;
-            const uint32_t y = s_key[i];
-            uint64_t uw = 0, qw = 0;
-            if (y != KEY_EMPTY) {
-                if (GROUP == OTTO_COVIS_GROUP_TIME)
-                    qw = 65536ull * s_v[0][i] + (((uint64_t)s_v[2][i] << 32) | s_v[1][i]);
-                else
-                    uw = (uint64_t)s_v[0][i] * a.coef[j][0] + (uint64_t)s_v[1][i] * a.coef[j][1] +
-                         (uint64_t)s_v[2][i] * a.coef[j][2];
+        // keys of table slot i for every kind of this pass (the slot is read once)
+        auto slot_keys = [&](int i, K (&out)[PKD]) {
+            uint32_t y, v0, v1, v2;
+            if (PACKED) {
+                const uint64_t v = s_tab[i];
+                y = v == TAB_EMPTY ? KEY_EMPTY : (uint32_t)(v >> 36);
+                v0 = (uint32_t)v & 0xFFFu; v1 = (uint32_t)(v >> 12) & 0xFFFu; v2 = (uint32_t)(v >> 24) & 0xFFFu;
+            } else {
+                y = s_key[i];
+                v0 = s_v[0][i]; v1 = s_v[1][i]; v2 = s_v[2][i];
             }
-            kmake(key, uw, qw, y);
-            return key;
+#pragma unroll
+            for (int j = 0; j < PKD; ++j) {
+                uint64_t uw = 0, qw = 0;
+                if (y != KEY_EMPTY) {
+                    if (GROUP == OTTO_COVIS_GROUP_TIME) qw = 65536ull * v0 + (((uint64_t)v2 << 32) | v1);
+                    else uw = (uint64_t)v0 * a.coef[j][0] + (uint64_t)v1 * a.coef[j][1] + (uint64_t)v2 * a.coef[j][2];
+                }
+                kmake(out[j], uw, qw, y);
+            }
         };
         // sorted list (lane i = i-th best) of kind j -> output rows, or this partition's partial list
         auto emit = [&](int j, K best) {
@@ -847,7 +918,7 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
         if (a.debug_skip & 1) {
         } else if (lgR > 0 && a.pstart) {
             // heavy aid, records already bucketed by hash partition: contiguous coalesced reads
-            const uint64_t ps = a.pstart[it], pe = a.pstart[it + 1];
+            const uint64_t ps = cur.ps, pe = cur.pe;
             for (uint64_t i0 = ps + threadIdx.x; i0 < pe; i0 += 4 * THREADS) {
                 uint32_t rc[4], e[4];
 #pragma unroll
@@ -862,12 +933,14 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
                 if (s_ovf) break;
             }
         } else {
-            for_each_record<NW>(a.sorted_desc, a.rec, a.run_start[x], a.run_start[x + 1], wid, [&](uint32_t rc, uint64_t slot) {
+            for_each_record<NW>(a.sorted_desc, a.rec, cur.rb, cur.re, wid, [&](uint32_t rc, uint64_t slot) {
                 const uint32_t h = rec_hash(rc);
                 if (lgR == 0 || ((h >> pshift) & pmask) == part)
                     insert(rc, h, GROUP == OTTO_COVIS_GROUP_TIME ? a.tw[slot] : 0u);
             });
         }
+        // stage 2 of the next item (its item word has long arrived)
+        if (!DYNAMIC || threadIdx.x == 0) fetch_ranges(nx);
         __syncthreads();
         const bool ovf = s_ovf != 0;
         if (a.debug_skip & 2) {
@@ -880,39 +953,43 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
             }
         } else {
             constexpr int MPL = T / THREADS;
+            // keys of this lane's MPL slots for all kinds, lane-best per kind
+            K c[PKD][MPL];
+            K lb[PKD];
+            int bi[PKD];
+#pragma unroll
+            for (int j = 0; j < PKD; ++j) { kclear(lb[j]); bi[j] = 0; }
+#pragma unroll
+            for (int q = 0; q < MPL; ++q) {
+                K kk[PKD];
+                slot_keys(q * THREADS + threadIdx.x, kk);
+#pragma unroll
+                for (int j = 0; j < PKD; ++j) {
+                    c[j][q] = kk[j];
+                    if (kbetter(kk[j], lb[j])) { lb[j] = kk[j]; bi[j] = q; }
+                }
+            }
             if (NW == 1) {
                 // ---- one wave owns the whole table: select per kind, write -------------------------
 #pragma unroll
-                for (int j = 0; j < PK; ++j) {
+                for (int j = 0; j < PKD; ++j) {
                     if (j >= a.nk) continue;
-                    K c[MPL];
-#pragma unroll
-                    for (int q = 0; q < MPL; ++q) c[q] = slot_key(q * THREADS + threadIdx.x, j);
                     K best;
-                    wave_topk_select<MPL, K>(c, a.k, best);
+                    wave_topk_select<MPL, K>(c[j], a.k, best);
                     emit(j, best);
                 }
             } else {
-                // ---- block-wide: ONE sort per kind. P1 every lane: keys of its MPL slots, lane-best to LDS.
+                // ---- block-wide: ONE sort per kind. P1 every lane: lane-best to LDS.
                 //      P2 wave j: top-k of the THREADS lane-bests, publish the k-th as threshold.
                 //      P3 every lane: the (rare) other candidates above the threshold go to a small list.
                 //      P4 wave j: insert them, emit. P3/P4 repeat only if the list overflowed. -------------
-                K c[PKD][MPL];
 #pragma unroll
                 for (int j = 0; j < PKD; ++j) {
                     if (j >= a.nk) continue;
-                    K lb;
-                    kclear(lb);
-                    int bi = 0;
-#pragma unroll
-                    for (int q = 0; q < MPL; ++q) {
-                        c[j][q] = slot_key(q * THREADS + threadIdx.x, j);
-                        if (kbetter(c[j][q], lb)) { lb = c[j][q]; bi = q; }
-                    }
 #pragma unroll
                     for (int q = 0; q < MPL; ++q)
-                        if (q == bi) kclear(c[j][q]);
-                    kstore(lb, &s_lbw[j][threadIdx.x], &s_lby[0][WIDE ? threadIdx.x : 0]);
+                        if (q == bi[j]) kclear(c[j][q]);
+                    kstore(lb[j], &s_lbw[j][threadIdx.x], &s_lby[0][WIDE ? threadIdx.x : 0]);
                 }
                 if (threadIdx.x < PK) s_nex[threadIdx.x] = 0;
                 if (threadIdx.x == 0) s_more = 0;
@@ -972,9 +1049,16 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
                 if (merger) emit(wid, best);
             }
         }
-        if (THREADS == S_THREADS) {
-            it += gridDim.x;
-            __syncthreads();
+        // ---- hand the prefetched next item over ----
+        if (DYNAMIC) {
+            __syncthreads();                       // every thread is done with s_cur's consumers and the table
+            if (threadIdx.x == 0) {
+                s_cur = nx;
+                idx_next = idx_far;                                   // dequeued one iteration ago
+                idx_far = atomicAdd(a.work_counter, 1u);              // consumed one iteration from now
+            }
+        } else {
+            cur = nx;
         }
     }
 }
@@ -1345,12 +1429,12 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
     if (bin == 0) {
         uint32_t grid = a.n_items < 256u * 20u ? a.n_items : 256u * 20u;
         tbegin(c, OTTO_COVIS_T_REDUCE_S, s);
-        k_reduce<S_LOG2T, S_THREADS, GROUP><<<grid, S_THREADS, 0, s>>>(a);
+        k_reduce<S_LOG2T, S_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME><<<grid, S_THREADS, 0, s>>>(a);
         tend(c, OTTO_COVIS_T_REDUCE_S, s);
     } else if (bin == 1) {
-        uint32_t grid = a.n_items < 256u * 2u ? a.n_items : 256u * 2u;
+        uint32_t grid = a.n_items < 256u * 4u ? a.n_items : 256u * 4u;
         tbegin(c, OTTO_COVIS_T_REDUCE_M, s);
-        k_reduce<M_LOG2T, M_THREADS, GROUP><<<grid, M_THREADS, 0, s>>>(a);
+        k_reduce<M_LOG2T, M_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME><<<grid, M_THREADS, 0, s>>>(a);
         tend(c, OTTO_COVIS_T_REDUCE_M, s);
     } else {
         a.pstart = nullptr;
@@ -1384,7 +1468,7 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
         }
         uint32_t grid = a.n_items < 256u ? a.n_items : 256u;
         tbegin(c, OTTO_COVIS_T_REDUCE_L, s);
-        k_reduce<L_LOG2T, L_THREADS, GROUP><<<grid, L_THREADS, 0, s>>>(a);
+        k_reduce<L_LOG2T, L_THREADS, GROUP, false><<<grid, L_THREADS, 0, s>>>(a);
         tend(c, OTTO_COVIS_T_REDUCE_L, s);
         OTTO_HIP(hipGetLastError());
         tbegin(c, OTTO_COVIS_T_MERGE, s);
