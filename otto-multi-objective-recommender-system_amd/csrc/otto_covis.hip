@@ -305,14 +305,20 @@ __global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
 constexpr int CNT_REC_BITS = 36;                      // cnt64[x] = runs << 36 | records
 constexpr uint64_t CNT_REC_MASK = (1ull << CNT_REC_BITS) - 1;
 
+// One returning 64-bit atomic per run: it accumulates (runs, records) of aid_x AND hands the run its rank
+// inside the aid (the previous run count), so the scatter below needs no second atomic.
 __global__ void k_hist_runs(const uint32_t* run_x, const uint64_t* run_desc, int64_t n_slots, uint64_t* cnt64,
-                            uint32_t n_aids) {
+                            uint32_t* run_rank, uint32_t n_aids) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t d = run_desc[i];
         const uint64_t len = d & 0xFFull;
         if (len) {
             const uint32_t x = run_x[i];
-            if (x < n_aids) atomicAdd((unsigned long long*)&cnt64[x], (unsigned long long)((1ull << CNT_REC_BITS) | len));
+            if (x < n_aids) {
+                const unsigned long long old =
+                    atomicAdd((unsigned long long*)&cnt64[x], (unsigned long long)((1ull << CNT_REC_BITS) | len));
+                run_rank[i] = (uint32_t)(old >> CNT_REC_BITS);
+            }
         }
     }
 }
@@ -326,16 +332,13 @@ struct RecCount {
     __device__ uint64_t operator()(int64_t x) const { return cnt64[x] & CNT_REC_MASK; }
 };
 
-__global__ void k_scatter_runs(const uint32_t* run_x, const uint64_t* run_desc, int64_t n_slots,
-                               const uint64_t* run_start, uint32_t* cursor, uint64_t* sorted_desc, uint32_t n_aids) {
+__global__ void k_scatter_runs(const uint32_t* run_x, const uint64_t* run_desc, const uint32_t* run_rank, int64_t n_slots,
+                               const uint64_t* run_start, uint64_t* sorted_desc, uint32_t n_aids) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t d = run_desc[i];
         if (d & 0xFFull) {
             const uint32_t x = run_x[i];
-            if (x < n_aids) {
-                const uint32_t c = atomicAdd(&cursor[x], 1u);
-                sorted_desc[run_start[x] + c] = d;
-            }
+            if (x < n_aids) sorted_desc[run_start[x] + run_rank[i]] = d;
         }
     }
 }
@@ -1171,7 +1174,7 @@ struct otto_covis_ctx {
     DevBuf pair_base, ev_base, partial, cls_pos[3], sess_list;
     // index
     bool index_valid = false;
-    DevBuf cnt64, run_start, cursor, sorted_desc, item_start, boost, flag, counters;
+    DevBuf cnt64, run_start, run_rank, sorted_desc, item_start, boost, flag, counters;
     DevBuf items[3];
     uint64_t n_items[3] = {0, 0, 0};
     uint64_t bin_pairs[3] = {0, 0, 0};
@@ -1228,7 +1231,7 @@ extern "C" void otto_covis_destroy(otto_covis_ctx* c) {
     if (!c) return;
     DevBuf* all[] = {&c->rec, &c->tw, &c->run_x, &c->run_desc, &c->pair_base, &c->ev_base, &c->partial, &c->cnt64,
                      &c->cls_pos[0], &c->cls_pos[1], &c->cls_pos[2], &c->sess_list,
-                     &c->run_start, &c->cursor, &c->sorted_desc, &c->item_start, &c->boost, &c->flag, &c->counters,
+                     &c->run_start, &c->run_rank, &c->sorted_desc, &c->item_start, &c->boost, &c->flag, &c->counters,
                      &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->exp_run_pos, &c->exp_rec_pos,
                      &c->litem_start, &c->chunks, &c->pcount, &c->pcursor, &c->pstart, &c->prec, &c->ptw};
     for (DevBuf* b : all) b->release();
@@ -1371,19 +1374,19 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
     OTTO_TRY(c->cnt64.ensure((size_t)n_aids * 8, 0, s));
     OTTO_TRY(c->run_start.ensure((size_t)(n_aids + 1) * 8, 0, s));
     OTTO_TRY(c->item_start.ensure((size_t)(n_aids + 1) * 8, 0, s));
-    OTTO_TRY(c->cursor.ensure((size_t)n_aids * 4, 0, s));
+    OTTO_TRY(c->run_rank.ensure((size_t)(c->run_used ? c->run_used : 1) * 4, 0, s));
     OTTO_TRY(c->boost.ensure((size_t)n_aids, 0, s));
     OTTO_TRY(c->flag.ensure((size_t)n_aids * 4, 0, s));
     OTTO_TRY(c->counters.ensure(64, 0, s));
     OTTO_TRY(c->partial.ensure(scan_partial_bytes((int64_t)n_aids), 0, s));
     OTTO_HIP(hipMemsetAsync(c->cnt64.p, 0, (size_t)n_aids * 8, s));
-    OTTO_HIP(hipMemsetAsync(c->cursor.p, 0, (size_t)n_aids * 4, s));
     OTTO_HIP(hipMemsetAsync(c->boost.p, 0, (size_t)n_aids, s));
     OTTO_HIP(hipMemsetAsync(c->flag.p, 0, (size_t)n_aids * 4, s));
     const int64_t n_slots = (int64_t)c->run_used;
     if (n_slots) {
         int grid = (int)((n_slots + 255) / 256 < 256 * 32 ? (n_slots + 255) / 256 : 256 * 32);
-        k_hist_runs<<<grid, 256, 0, s>>>(c->run_x.as<uint32_t>(), c->run_desc.as<uint64_t>(), n_slots, c->cnt64.as<uint64_t>(), n_aids);
+        k_hist_runs<<<grid, 256, 0, s>>>(c->run_x.as<uint32_t>(), c->run_desc.as<uint64_t>(), n_slots, c->cnt64.as<uint64_t>(),
+                                         c->run_rank.as<uint32_t>(), n_aids);
         OTTO_HIP(hipGetLastError());
     }
     // total pairs (records) and runs
@@ -1398,9 +1401,8 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
     OTTO_TRY(c->sorted_desc.ensure((size_t)(c->n_runs ? c->n_runs : 1) * 8, 0, s));
     if (n_slots) {
         int grid = (int)((n_slots + 255) / 256 < 256 * 32 ? (n_slots + 255) / 256 : 256 * 32);
-        k_scatter_runs<<<grid, 256, 0, s>>>(c->run_x.as<uint32_t>(), c->run_desc.as<uint64_t>(), n_slots,
-                                            c->run_start.as<uint64_t>(), c->cursor.as<uint32_t>(),
-                                            c->sorted_desc.as<uint64_t>(), n_aids);
+        k_scatter_runs<<<grid, 256, 0, s>>>(c->run_x.as<uint32_t>(), c->run_desc.as<uint64_t>(), c->run_rank.as<uint32_t>(),
+                                            n_slots, c->run_start.as<uint64_t>(), c->sorted_desc.as<uint64_t>(), n_aids);
         OTTO_HIP(hipGetLastError());
     }
     for (int bin = 0; bin < 3; ++bin) {
