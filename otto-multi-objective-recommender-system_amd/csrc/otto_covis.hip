@@ -225,6 +225,14 @@ __global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
             pbase = a.pair_base[s];
             ebase = a.ev_base[s];
         }
+        // wave-uniform trip count: the longest window of this wave
+        int nmax = 0;
+#pragma unroll
+        for (int q = 0; q < WPW; ++q) {
+            const int nq = __builtin_amdgcn_readlane(n, q * G);
+            nmax = nq > nmax ? nq : nmax;
+        }
+        const int nmax4 = (nmax + 3) & ~3;
         // ---- A ----
         uint32_t aid = 0xFFFFFFFFu, ty = 0, extra = 0;
         int32_t t = 0;
@@ -237,28 +245,34 @@ __global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
         ev[g] = make_uint4(aid, (uint32_t)t, ty, extra);
         wave_lds_sync();
         int cls = g;
-        for (int j = G - 1; j >= 0; --j) {
-            if (__ballot(j < n) == 0) continue;
-            if (j < n && ev[j].x == aid) cls = j;
+        for (int j0 = nmax4 - 4; j0 >= 0; j0 -= 4) {      // LDS reads four at a time: latency paid once per group
+            uint32_t ax[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ax[u] = ev[(j0 + u) & (G - 1)].x;
+#pragma unroll
+            for (int u = 3; u >= 0; --u)
+                if (j0 + u < n && ax[u] == aid) cls = j0 + u;
         }
         if (g < n) {
             ev[g].z = ty | ((uint32_t)cls << 8);
             if (FILT)
                 for (int q = 0; q < FBW; ++q) FB[g * FBW + q] = 0;
         }
-        for (int r = 0; r < G; ++r) {
-            if (__ballot(r < n) == 0) break;
+        for (int r = 0; r < nmax; ++r)
             if (r < n) M[r * G + g] = M_EMPTY;
-        }
         wave_lds_sync();
         // ---- B ----
-        for (int i = 0; i < G; ++i) {
-            if (__ballot(i < n) == 0) break;
-            if (i < n && g < n) {
-                const uint4 e = ev[i];
+        for (int i0 = 0; i0 < nmax; i0 += 4) {
+            uint4 e4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) e4[u] = ev[(i0 + u) & (G - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u;
+                const uint4 e = e4[u];
                 int dt = (int)e.y - t;
                 dt = dt < 0 ? -dt : dt;
-                if (e.x != aid && dt <= a.max_gap) {
+                if (i < n && g < n && e.x != aid && dt <= a.max_gap) {
                     const uint32_t ci = e.z >> 8;
                     atomicMin(&M[ci * G + cls], (uint32_t)((i << 5) | g));
                     if (FILT) {
@@ -273,23 +287,29 @@ __global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
         wave_lds_sync();
         // ---- C ----
         uint32_t off = 0, my_off = 0, my_cnt = 0;
-        for (int r = 0; r < G; ++r) {
-            if (__ballot(r < n) == 0) break;
-            const uint32_t e = (r < n && g < n) ? M[r * G + g] : M_EMPTY;
-            const bool has = e != M_EMPTY;
-            const uint32_t hm = (uint32_t)((__ballot(has) >> grp_shift) & gmask);
-            const uint32_t cnt = __popc(hm);
-            if (has) {
-                const uint32_t rank = __popc(hm & ((1u << g) - 1u));
-                const uint32_t i = e >> 5, j = e & 31u;
-                const uint32_t tyj = ev[j].z & 0xFFu;
-                const uint32_t fb = FILT ? (FB[r * FBW + (g >> 3)] >> ((g & 7) * 4)) & 0xFu : 0u;
-                const uint64_t slot = a.rec_base + pbase + off + rank;
-                a.rec[slot] = aid | (tyj << REC_AID_BITS) | (fb << 28);
-                if (TIME) a.tw[slot] = ev[i].w;
+        for (int r0 = 0; r0 < nmax; r0 += 4) {
+            uint32_t m4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m4[u] = (r0 + u < n && g < n) ? M[((r0 + u) & (G - 1)) * G + g] : M_EMPTY;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + u;
+                const uint32_t e = m4[u];
+                const bool has = e != M_EMPTY;
+                const uint32_t hm = (uint32_t)((__ballot(has) >> grp_shift) & gmask);
+                const uint32_t cnt = __popc(hm);
+                if (has) {
+                    const uint32_t rank = __popc(hm & ((1u << g) - 1u));
+                    const uint32_t i = e >> 5, j = e & 31u;
+                    const uint32_t tyj = ev[j].z & 0xFFu;
+                    const uint32_t fb = FILT ? (FB[r * FBW + (g >> 3)] >> ((g & 7) * 4)) & 0xFu : 0u;
+                    const uint64_t slot = a.rec_base + pbase + off + rank;
+                    a.rec[slot] = aid | (tyj << REC_AID_BITS) | (fb << 28);
+                    if (TIME) a.tw[slot] = ev[i].w;
+                }
+                if (g == r) { my_off = off; my_cnt = cnt; }
+                off += cnt;
             }
-            if (g == r) { my_off = off; my_cnt = cnt; }
-            off += cnt;
         }
         if (g < n) {
             a.run_x[a.run_base + ebase + g] = aid;
