@@ -145,6 +145,27 @@ def run(a, dev, rank, world):
         res['rmf_sparse_adam'] = {'value': round(nb * B / dtr, 1), 'unit': 'samples/s', 'ms_per_batch': round(1e3 * dtr / nb, 3),
                                   'config': f'MatrixFactorization MSELoss SparseAdam, {dr} factors, batch {B} (reference config.yaml)'}
         del E1, E2, st, er
+        # full-sort scoring (recbole/inference.py:334: test batches of 4096 sessions x all items), d = 128 (config 5)
+        from .engine import score_topk
+        Bs, ds = 4096, 128
+        Us = torch.randn(Bs, ds, device=dev, generator=g)
+        Vs = torch.randn(n_items + 1, ds, device=dev, generator=g)      # + PAD row 0
+        score_topk(Us, Vs, k=20, pad_col=0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 3
+        e0.record()
+        for _ in range(reps):
+            ids, sc = score_topk(Us, Vs, k=20, pad_col=0)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        flop = 2.0 * Bs * (n_items + 1) * ds
+        res['score_topk'] = {'value': round(Bs / (ms * 1e-3), 1), 'unit': 'sessions/s', 'ms_per_batch': round(ms, 3),
+                             'config': f'B={Bs} sessions x N={n_items + 1} items x d={ds} fp32, fused top-20, PAD column 0',
+                             'roofline': {'kernel': 'k_score<128> + k_score_merge', 'bound': 'mfma', 'achieved': round(flop / (ms * 1e-3) / 1e12, 2),
+                                          'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(flop / (ms * 1e-3) / 1e12 / 157.3, 4), 'traffic': None}}
+        del Us, Vs
         if a.cpu_sessions > 0:
             res['cpu_baseline'] = _cpu_baseline(U, V, users, items, n_items, 2_000_000)
     return res
