@@ -581,6 +581,59 @@ __device__ __forceinline__ void wave_topk_select(K (&c)[MPL], int k, K& best) {
     }
 }
 
+// NK independent selections at once (the kinds of one pass): the sorting networks are interleaved stage by
+// stage so each wave has NK independent dependency chains in flight (a single chain is latency-bound).
+template <int MPL, int NK, typename K>
+__device__ __forceinline__ void wave_topk_select_multi(K (&c)[NK][MPL], int nk, int k, K (&best)[NK]) {
+    const unsigned l = lane_id();
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        K lb = c[j][0];
+        int bi = 0;
+#pragma unroll
+        for (int i = 1; i < MPL; ++i)
+            if (kbetter(c[j][i], lb)) { lb = c[j][i]; bi = i; }
+#pragma unroll
+        for (int i = 0; i < MPL; ++i)
+            if (i == bi) kclear(c[j][i]);
+        best[j] = lb;
+    }
+#pragma unroll
+    for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+        for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+            const bool keep_better = ((l & jj) == 0) == ((l & kk) == 0);
+#pragma unroll
+            for (int j = 0; j < NK; ++j) {
+                const K o = kshfl_xor(best[j], jj);
+                if (keep_better ? kbetter(o, best[j]) : kbetter(best[j], o)) best[j] = o;
+            }
+        }
+    }
+    if (MPL > 1) {
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+            if (j >= nk) continue;
+            for (;;) {
+                const K thr = kshfl(best[j], k - 1);
+                K lb;
+                kclear(lb);
+                int bi = -1;
+#pragma unroll
+                for (int i = 0; i < MPL; ++i)
+                    if (kvalid(c[j][i]) && (bi < 0 || kbetter(c[j][i], lb))) { lb = c[j][i]; bi = i; }
+                const bool q = bi >= 0 && kbetter(lb, thr);
+                if (__ballot(q) == 0) break;
+#pragma unroll
+                for (int i = 0; i < MPL; ++i)
+                    if (i == bi) kclear(c[j][i]);
+                if (!q) kclear(lb);
+                wave_topk_push(best[j], lb, k);
+            }
+        }
+    }
+}
+
 // Visit every record of the runs [r0, r1). Runs are dealt round-robin to the NW waves of the workgroup
 // (wave w owns runs r0 + w, r0 + w + NW, ...): a wave fetches 64 of its run descriptors with one load, then
 // walks them two at a time (one per 32-lane half) with GATHER_U record loads in flight per lane, so an item
@@ -920,6 +973,7 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
                 uint64_t uw = 0, qw = 0;
                 if (y != KEY_EMPTY) {
                     if (GROUP == OTTO_COVIS_GROUP_TIME) qw = 65536ull * v0 + (((uint64_t)v2 << 32) | v1);
+                    else if (PACKED) uw = v0 * a.coef[j][0] + v1 * a.coef[j][1] + v2 * a.coef[j][2];   // 12-bit counts x 8-bit weights: 32-bit math
                     else uw = (uint64_t)v0 * a.coef[j][0] + (uint64_t)v1 * a.coef[j][1] + (uint64_t)v2 * a.coef[j][2];
                 }
                 kmake(out[j], uw, qw, y);
@@ -994,13 +1048,11 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
             }
             if (NW == 1) {
                 // ---- one wave owns the whole table: select per kind, write -------------------------
+                K bests[PKD];
+                wave_topk_select_multi<MPL, PKD, K>(c, a.nk, a.k, bests);
 #pragma unroll
-                for (int j = 0; j < PKD; ++j) {
-                    if (j >= a.nk) continue;
-                    K best;
-                    wave_topk_select<MPL, K>(c[j], a.k, best);
-                    emit(j, best);
-                }
+                for (int j = 0; j < PKD; ++j)
+                    if (j < a.nk) emit(j, bests[j]);
             } else {
                 // ---- block-wide: ONE sort per kind. P1 every lane: lane-best to LDS.
                 //      P2 wave j: top-k of the THREADS lane-bests, publish the k-th as threshold.
