@@ -40,7 +40,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--sessions', type=int, default=14_571_582, help='sessions per rank (full OTTO = 14,571,582)')
     ap.add_argument('--k', type=int, default=20)
-    ap.add_argument('--cpu-sessions', type=int, default=150_000, help='sample size of the cpu_baseline leg (0 = skip)')
+    ap.add_argument('--cpu-sessions', type=int, default=400_000, help='sample size of the cpu_baseline leg (0 = skip)')
     ap.add_argument('--no-mf', action='store_true')
     ap.add_argument('--mf-rows', type=int, default=200_000_000)
     ap.add_argument('--mf-factors', type=int, default=64)
@@ -88,11 +88,10 @@ def cpu_baseline(dev_data, n_sessions, k):
     except Exception:
         coc = None
     if coc is not None and coc.available():
-        cores = os.cpu_count() or 1
-        t0 = time.time()
-        pairs = coc.covis_topk_c(aid, ts, typ, off, dev_data['n_aids'], BENCH_KINDS, k=k, threads=cores)['P']
-        dt = time.time() - t0
-        impl = f'oracle/covis_oracle.c (OpenMP, {cores} threads)'
+        cores = min(os.cpu_count() or 1, 64)
+        r = coc.covis_topk_c(aid, ts, typ, off, dev_data['n_aids'], BENCH_KINDS, k=k, threads=cores, rows=False)
+        pairs, dt = r['P'], r['seconds_in_c']
+        impl = f'oracle/covis_oracle.c (gcc -O3, OpenMP, {cores} threads)'
     else:
         import covis_oracle as co
         cores = 1

@@ -98,3 +98,26 @@ def test_window_is_the_session_tail():
     off = np.array([0, 40], dtype=np.int64)
     got = co.covis_pairs_numpy(aid, ts, typ, off, co.CovisSpec(window=30, kinds=('click_click',)))['click_click']
     assert got[0].min() == 10 and len(got[0]) == 30 * 29
+
+
+def test_c_restatement_matches_numpy_and_hand_values():
+    """oracle/covis_oracle.c (the timed cpu_baseline) against the NumPy oracle and the hand-derived micro-sessions."""
+    import __graft_entry__ as g
+    g._run(['make', 'all'], os.path.join(g.ROOT, 'oracle'))
+    import covis_oracle_c as coc
+    assert coc.available()
+    ev = generate_sessions(1500, n_aids=300, seed=9)
+    want = co.covis_topk_numpy(ev.aid, ev.ts, ev.type, ev.sess_off, co.CovisSpec(), k=20)
+    st = {}
+    co.covis_pairs_numpy(ev.aid, ev.ts, ev.type, ev.sess_off, co.CovisSpec(kinds=('click_click',)), stats=st)
+    got = coc.covis_topk_c(ev.aid, ev.ts, ev.type, ev.sess_off, ev.n_aids, co.ALL_KINDS, k=20, threads=4)
+    assert got['P'] == st['P']
+    for kind in co.ALL_KINDS:
+        for a_, b_ in zip(got[kind], want[kind]):
+            assert np.array_equal(a_, b_), kind
+    aid, ts, typ, off = _micro()
+    got = coc.covis_topk_c(aid, ts, typ, off, 31, ('cart_weighted', 'time_weighted', 'cart_order'), k=20, threads=1)
+    d = dict(zip(zip(got['cart_weighted'][0].tolist(), got['cart_weighted'][1].tolist()), got['cart_weighted'][2].tolist()))
+    assert d == {p: w * Q for p, w in HAND['cart_weighted'].items()}
+    d = dict(zip(zip(got['time_weighted'][0].tolist(), got['time_weighted'][1].tolist()), got['time_weighted'][2].tolist()))
+    assert d == HAND_TIME
