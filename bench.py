@@ -106,6 +106,36 @@ def cpu_baseline(dev_data, n_sessions, k):
                       f'{impl}, {dt:.1f} s wall', 'host_cores_available': os.cpu_count()}
 
 
+def mf_cpu_baseline(U, V, users, items, n_items, sample):
+    """PyTorch-CPU restatement of the BPR batch step (oracle/mf_oracle.py arithmetic) on a bounded sample."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import mf_oracle as mo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    u = users[:sample].cpu()
+    i = items[:sample].cpu()
+    uu, inv = torch.unique(u, return_inverse=True)          # only the touched user rows travel to the host
+    Uc = U[uu.to(U.device)].cpu()
+    Vc = V.cpu()
+    t0 = time.time()
+    j = torch.from_numpy(mo.bpr_negatives(42, 0, 0, i.numpy()[:20000], n_items))       # sampler rate measured on 20k rows
+    t_neg = (time.time() - t0) / 20000 * sample
+    j = torch.randint(0, n_items, (sample,))
+    t0 = time.time()
+    eu, ei, ej = Uc[inv], Vc[i], Vc[j]
+    x = (eu * (ei - ej)).sum(1)
+    s = torch.sigmoid(-x)[:, None]
+    Uc.index_add_(0, inv, 0.05 * s * (ei - ej))
+    Vc.index_add_(0, i, 0.05 * s * eu)
+    Vc.index_add_(0, j, -0.05 * s * eu)
+    dt = time.time() - t0
+    return {'value': round(sample / dt, 1), 'unit': 'triplets/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{sample} triplets of the same stream, PyTorch-CPU gather/dot/sigmoid/index_add_ '
+                      f'({dt:.2f} s; pure-Python counter RNG of the oracle excluded: {t_neg:.1f} s extrapolated)'}
+
+
+
 def main():
     a = parse()
     import torch
@@ -228,7 +258,7 @@ def main():
         if bench_mf is not None:
             del builder, eng, out
             torch.cuda.empty_cache()
-            mf = bench_mf.run(a, dev, rank, world)
+            mf = bench_mf.run(a, dev, rank, world, mf_cpu_baseline if (rank == 0 and world == 1 and a.cpu_sessions > 0) else None)
             if rank == 0:
                 result['mf'] = mf
     if rank == 0 and world == 1 and a.cpu_sessions > 0:

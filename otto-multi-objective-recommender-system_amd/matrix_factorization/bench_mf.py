@@ -4,8 +4,6 @@ OTTO-shape (session, aid) stream, plus the reference-config R-MF (SparseAdam) sa
 Weak scaling for N > 1: every rank owns ``--mf-rows`` rows of its own session chunk (user rows are
 rank-private), the item table is replicated and its deltas are all-reduced over RCCL every
 ``SYNC_EVERY`` launches (``bpr.sync_item_table``)."""
-import os
-import sys
 import time
 
 import numpy as np
@@ -15,37 +13,7 @@ SYNC_EVERY = 4
 HBM_PEAK_GBS = 8000.0
 
 
-def _cpu_baseline(U, V, users, items, n_items, sample):
-    """PyTorch-CPU restatement of the BPR batch step (oracle/mf_oracle.py arithmetic) on a bounded sample."""
-    import torch
-    ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import mf_oracle as mo
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    u = users[:sample].cpu()
-    i = items[:sample].cpu()
-    uu, inv = torch.unique(u, return_inverse=True)          # only the touched user rows travel to the host
-    Uc = U[uu.to(U.device)].cpu()
-    Vc = V.cpu()
-    t0 = time.time()
-    j = torch.from_numpy(mo.bpr_negatives(42, 0, 0, i.numpy()[:20000], n_items))       # sampler rate measured on 20k rows
-    t_neg = (time.time() - t0) / 20000 * sample
-    j = torch.randint(0, n_items, (sample,))
-    t0 = time.time()
-    eu, ei, ej = Uc[inv], Vc[i], Vc[j]
-    x = (eu * (ei - ej)).sum(1)
-    s = torch.sigmoid(-x)[:, None]
-    Uc.index_add_(0, inv, 0.05 * s * (ei - ej))
-    Vc.index_add_(0, i, 0.05 * s * eu)
-    Vc.index_add_(0, j, -0.05 * s * eu)
-    dt = time.time() - t0
-    return {'value': round(sample / dt, 1), 'unit': 'triplets/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{sample} triplets of the same stream, PyTorch-CPU gather/dot/sigmoid/index_add_ '
-                      f'({dt:.2f} s; pure-Python counter RNG of the oracle excluded: {t_neg:.1f} s extrapolated)'}
-
-
-def run(a, dev, rank, world):
+def run(a, dev, rank, world, cpu_baseline_fn=None):
     import torch
     import torch.distributed as dist
     from ..synth import generate_sessions_torch, OTTO_N_AIDS, OTTO_N_SESSIONS
@@ -166,6 +134,6 @@ def run(a, dev, rank, world):
                              'roofline': {'kernel': 'k_score<128> + k_score_merge', 'bound': 'mfma', 'achieved': round(flop / (ms * 1e-3) / 1e12, 2),
                                           'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(flop / (ms * 1e-3) / 1e12 / 157.3, 4), 'traffic': None}}
         del Us, Vs
-        if a.cpu_sessions > 0:
-            res['cpu_baseline'] = _cpu_baseline(U, V, users, items, n_items, 2_000_000)
+        if cpu_baseline_fn is not None:
+            res['cpu_baseline'] = cpu_baseline_fn(U, V, users, items, n_items, 2_000_000)
     return res
