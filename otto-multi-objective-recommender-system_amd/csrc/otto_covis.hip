@@ -581,6 +581,24 @@ __device__ __forceinline__ void wave_topk_select(K (&c)[MPL], int k, K& best) {
     }
 }
 
+// NK independent 64-lane sorts, networks interleaved stage by stage (NK dependency chains in flight)
+template <int NK, typename K>
+__device__ __forceinline__ void wave_bitonic_sort_multi(K (&v)[NK]) {
+    const unsigned l = lane_id();
+#pragma unroll
+    for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+        for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+            const bool keep_better = ((l & jj) == 0) == ((l & kk) == 0);
+#pragma unroll
+            for (int j = 0; j < NK; ++j) {
+                const K o = kshfl_xor(v[j], jj);
+                if (keep_better ? kbetter(o, v[j]) : kbetter(v[j], o)) v[j] = o;
+            }
+        }
+    }
+}
+
 // NK independent selections at once (the kinds of one pass): the sorting networks are interleaved stage by
 // stage so each wave has NK independent dependency chains in flight (a single chain is latency-bound).
 template <int MPL, int NK, typename K>
@@ -638,8 +656,7 @@ __device__ __forceinline__ void wave_topk_select_multi(K (&c)[NK][MPL], int nk, 
 // (wave w owns runs r0 + w, r0 + w + NW, ...): a wave fetches 64 of its run descriptors with one load, then
 // walks them two at a time (one per 32-lane half) with GATHER_U record loads in flight per lane, so an item
 // of a few dozen runs costs two or three dependent memory round trips instead of one per run.
-constexpr int GATHER_U = 8;
-template <int NW, typename F>
+template <int NW, int GATHER_U, typename F>
 __device__ __forceinline__ void for_each_record(const uint64_t* sorted_desc, const uint32_t* rec, uint64_t r0, uint64_t r1,
                                                 int wid, F f) {
     const unsigned lane = lane_id();
@@ -729,7 +746,7 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
         if (re > a.run_start[x + 1]) re = a.run_start[x + 1];
         if (lgR > PART_LDS_LOG2R || (a.cnt64[x] & CNT_REC_MASK) >= (1ull << 32)) {
             // more partitions than LDS counters: global atomics per record (giant aids only)
-            for_each_record<NW>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t slot) {
+            for_each_record<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t slot) {
                 const uint64_t g = g0 + ((rec_hash(rc) >> pshift) & pmask);
                 if (!SCATTER) atomicAdd(&a.pcount[g], 1u);
                 else {
@@ -742,7 +759,7 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
         }
         for (uint32_t p = threadIdx.x; p < R; p += 256) s_cnt[p] = 0;
         __syncthreads();
-        for_each_record<NW>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t) {
+        for_each_record<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t) {
             atomicAdd(&s_cnt[(rec_hash(rc) >> pshift) & pmask], 1u);
         });
         __syncthreads();
@@ -758,7 +775,7 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
                 s_cnt[p] = 0;
             }
             __syncthreads();
-            for_each_record<NW>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t slot) {
+            for_each_record<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t slot) {
                 const uint32_t p = (rec_hash(rc) >> pshift) & pmask;
                 const uint64_t pos = x_base + s_base[p] + atomicAdd(&s_cnt[p], 1u);
                 a.prec[pos] = rc;
@@ -811,8 +828,8 @@ struct ItemDesc {      // everything a workgroup needs about its item, fetched o
     uint64_t ps, pe;   // bucket range (partitioned heavy aids)
 };
 
-template <int LOG2T, int THREADS, int GROUP, bool PACKED>
-__global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
+template <int LOG2T, int THREADS, int GROUP, bool PACKED, int MINW, int GU>
+__global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     constexpr int T = 1 << LOG2T;
     constexpr int NW = THREADS / 64;
     using K = typename std::conditional<GROUP == OTTO_COVIS_GROUP_TIME, KeyW, KeyN>::type;
@@ -1010,7 +1027,7 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
                 if (s_ovf) break;
             }
         } else {
-            for_each_record<NW>(a.sorted_desc, a.rec, cur.rb, cur.re, wid, [&](uint32_t rc, uint64_t slot) {
+            for_each_record<NW, GU>(a.sorted_desc, a.rec, cur.rb, cur.re, wid, [&](uint32_t rc, uint64_t slot) {
                 const uint32_t h = rec_hash(rc);
                 if (lgR == 0 || ((h >> pshift) & pmask) == part)
                     insert(rc, h, GROUP == OTTO_COVIS_GROUP_TIME ? a.tw[slot] : 0u);
@@ -1030,42 +1047,64 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
             }
         } else {
             constexpr int MPL = T / THREADS;
-            // keys of this lane's MPL slots for all kinds, lane-best per kind
-            K c[PKD][MPL];
+            static_assert(MPL <= 32, "consumed-slot bitmask is 32 bits");
+            // Candidate keys are NOT cached in registers (3 kinds x MPL keys would cost ~100 VGPRs and halve the
+            // resident workgroups): they are recomputed from the LDS table when needed (one read + a few 32-bit
+            // ops), with a per-kind bitmask of the slots of this lane that are already in a list.
             K lb[PKD];
-            int bi[PKD];
+            uint32_t done[PKD];
+            {
+                int bi[PKD];
 #pragma unroll
-            for (int j = 0; j < PKD; ++j) { kclear(lb[j]); bi[j] = 0; }
+                for (int j = 0; j < PKD; ++j) { kclear(lb[j]); bi[j] = 0; }
+#pragma unroll 2
+                for (int q = 0; q < MPL; ++q) {      // NOT fully unrolled: keeps a couple of slots in flight, not all MPL
+                    K kk[PKD];
+                    slot_keys(q * THREADS + threadIdx.x, kk);
 #pragma unroll
-            for (int q = 0; q < MPL; ++q) {
-                K kk[PKD];
-                slot_keys(q * THREADS + threadIdx.x, kk);
-#pragma unroll
-                for (int j = 0; j < PKD; ++j) {
-                    c[j][q] = kk[j];
-                    if (kbetter(kk[j], lb[j])) { lb[j] = kk[j]; bi[j] = q; }
+                    for (int j = 0; j < PKD; ++j)
+                        if (kbetter(kk[j], lb[j])) { lb[j] = kk[j]; bi[j] = q; }
                 }
+#pragma unroll
+                for (int j = 0; j < PKD; ++j) done[j] = 1u << bi[j];
             }
             if (NW == 1) {
-                // ---- one wave owns the whole table: select per kind, write -------------------------
+                // ---- one wave owns the whole table: sort the lane-bests of all kinds (interleaved networks),
+                //      then insert the few remaining candidates that still beat the k-th entry -------------
                 K bests[PKD];
-                wave_topk_select_multi<MPL, PKD, K>(c, a.nk, a.k, bests);
 #pragma unroll
-                for (int j = 0; j < PKD; ++j)
-                    if (j < a.nk) emit(j, bests[j]);
+                for (int j = 0; j < PKD; ++j) bests[j] = lb[j];
+                wave_bitonic_sort_multi<PKD, K>(bests);
+#pragma unroll
+                for (int j = 0; j < PKD; ++j) {
+                    if (j >= a.nk) continue;
+                    for (;;) {
+                        const K thr = kshfl(bests[j], a.k - 1);
+                        K cb;
+                        kclear(cb);
+                        int ci = -1;
+#pragma unroll 1
+                        for (int q = 0; q < MPL; ++q) {
+                            if ((done[j] >> q) & 1u) continue;
+                            K kk[PKD];
+                            slot_keys(q * THREADS + threadIdx.x, kk);
+                            if (kvalid(kk[j]) && (ci < 0 || kbetter(kk[j], cb))) { cb = kk[j]; ci = q; }
+                        }
+                        const bool qual = ci >= 0 && kbetter(cb, thr);
+                        if (__ballot(qual) == 0) break;
+                        if (qual) done[j] |= 1u << ci; else kclear(cb);
+                        wave_topk_push(bests[j], cb, a.k);
+                    }
+                    emit(j, bests[j]);
+                }
             } else {
                 // ---- block-wide: ONE sort per kind. P1 every lane: lane-best to LDS.
                 //      P2 wave j: top-k of the THREADS lane-bests, publish the k-th as threshold.
                 //      P3 every lane: the (rare) other candidates above the threshold go to a small list.
                 //      P4 wave j: insert them, emit. P3/P4 repeat only if the list overflowed. -------------
 #pragma unroll
-                for (int j = 0; j < PKD; ++j) {
-                    if (j >= a.nk) continue;
-#pragma unroll
-                    for (int q = 0; q < MPL; ++q)
-                        if (q == bi[j]) kclear(c[j][q]);
-                    kstore(lb[j], &s_lbw[j][threadIdx.x], &s_lby[0][WIDE ? threadIdx.x : 0]);
-                }
+                for (int j = 0; j < PKD; ++j)
+                    if (j < a.nk) kstore(lb[j], &s_lbw[j][threadIdx.x], &s_lby[0][WIDE ? threadIdx.x : 0]);
                 if (threadIdx.x < PK) s_nex[threadIdx.x] = 0;
                 if (threadIdx.x == 0) s_more = 0;
                 __syncthreads();
@@ -1083,18 +1122,20 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
                 }
                 for (;;) {
                     __syncthreads();
+                    K thr[PKD];
 #pragma unroll
-                    for (int j = 0; j < PKD; ++j) {
-                        if (j >= a.nk) continue;
-                        K thr;
-                        kload(thr, s_thrw[j], s_thry[j]);
+                    for (int j = 0; j < PKD; ++j) kload(thr[j], s_thrw[j], s_thry[j]);
+#pragma unroll 2
+                    for (int q = 0; q < MPL; ++q) {
+                        K kk[PKD];
+                        slot_keys(q * THREADS + threadIdx.x, kk);
 #pragma unroll
-                        for (int q = 0; q < MPL; ++q) {
-                            if (kvalid(c[j][q]) && kbetter(c[j][q], thr)) {
+                        for (int j = 0; j < PKD; ++j) {
+                            if (j < a.nk && !((done[j] >> q) & 1u) && kvalid(kk[j]) && kbetter(kk[j], thr[j])) {
                                 const uint32_t pos = atomicAdd(&s_nex[j], 1u);
                                 if (pos < (uint32_t)EXCAP) {
-                                    kstore(c[j][q], &s_exw[j][pos], &s_exy[0][WIDE ? pos : 0]);
-                                    kclear(c[j][q]);
+                                    kstore(kk[j], &s_exw[j][pos], &s_exy[0][WIDE ? pos : 0]);
+                                    done[j] |= 1u << q;
                                 } else {
                                     s_more = 1;
                                 }
@@ -1112,8 +1153,8 @@ __global__ __launch_bounds__(THREADS) void k_reduce(ReduceArgs a) {
                             wave_topk_push(best, cand, a.k);
                         }
                         if (more) {
-                            const K thr = kshfl(best, a.k - 1);
-                            if (lane == 0) kstore(thr, &s_thrw[wid], &s_thry[wid]);
+                            const K thr2 = kshfl(best, a.k - 1);
+                            if (lane == 0) kstore(thr2, &s_thrw[wid], &s_thry[wid]);
                         }
                     }
                     if (!more) break;
@@ -1503,12 +1544,12 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
     if (bin == 0) {
         uint32_t grid = a.n_items < 256u * 20u ? a.n_items : 256u * 20u;
         tbegin(c, OTTO_COVIS_T_REDUCE_S, s);
-        k_reduce<S_LOG2T, S_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME><<<grid, S_THREADS, 0, s>>>(a);
+        k_reduce<S_LOG2T, S_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, 5, 8><<<grid, S_THREADS, 0, s>>>(a);
         tend(c, OTTO_COVIS_T_REDUCE_S, s);
     } else if (bin == 1) {
         uint32_t grid = a.n_items < 256u * 4u ? a.n_items : 256u * 4u;
         tbegin(c, OTTO_COVIS_T_REDUCE_M, s);
-        k_reduce<M_LOG2T, M_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME><<<grid, M_THREADS, 0, s>>>(a);
+        k_reduce<M_LOG2T, M_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, (GROUP != OTTO_COVIS_GROUP_TIME ? 4 : 2), 4><<<grid, M_THREADS, 0, s>>>(a);
         tend(c, OTTO_COVIS_T_REDUCE_M, s);
     } else {
         a.pstart = nullptr;
@@ -1542,7 +1583,7 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
         }
         uint32_t grid = a.n_items < 256u ? a.n_items : 256u;
         tbegin(c, OTTO_COVIS_T_REDUCE_L, s);
-        k_reduce<L_LOG2T, L_THREADS, GROUP, false><<<grid, L_THREADS, 0, s>>>(a);
+        k_reduce<L_LOG2T, L_THREADS, GROUP, false, 4, 2><<<grid, L_THREADS, 0, s>>>(a);
         tend(c, OTTO_COVIS_T_REDUCE_L, s);
         OTTO_HIP(hipGetLastError());
         tbegin(c, OTTO_COVIS_T_MERGE, s);
