@@ -40,7 +40,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--sessions', type=int, default=14_571_582, help='sessions per rank (full OTTO = 14,571,582)')
     ap.add_argument('--k', type=int, default=20)
-    ap.add_argument('--cpu-sessions', type=int, default=400_000, help='sample size of the cpu_baseline leg (0 = skip)')
+    ap.add_argument('--cpu-sessions', type=int, default=4_000_000, help='sample size of the cpu_baseline leg (0 = skip)')
     ap.add_argument('--no-mf', action='store_true')
     ap.add_argument('--mf-rows', type=int, default=200_000_000)
     ap.add_argument('--mf-factors', type=int, default=64)
