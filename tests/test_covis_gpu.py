@@ -273,3 +273,72 @@ def test_sharded_builder_two_ranks_on_one_gpu(gpu_device):
             parts.append(rows[kind])
         merged[kind] = tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
     _assert_rows_equal(merged, want, cs.ALL_KINDS)
+
+
+def test_full_otto_scale_properties(gpu_device):
+    """BASELINE.json configs[1] size (14,571,582 sessions, ~243 M events, 1,855,603 aids): too big for the
+    oracle, so parity is asserted through size-independent properties:
+      * two different code paths agree bit for bit: one feed + partitioned heavy aids  vs  7 session chunks
+        + the filter/re-read path for heavy aids (option partition=0);
+      * every list is sorted by (W desc, aid_y asc), has no duplicate aid_y, never contains aid_x, n <= k;
+      * `click_click` (symmetric mask, unit weight) is symmetric: if y is listed for x and x for y the weights match;
+      * for type-weighted kinds W is a multiple of 65536 and cart_weighted >= click_weighted-implied bounds;
+      * the pair count equals the sum of run lengths and is identical in both runs."""
+    import torch
+    from otto_amd.synth import generate_sessions_torch, OTTO_N_AIDS, OTTO_N_SESSIONS
+    from otto_amd.covisitation.engine import CovisBuilder
+    d = generate_sessions_torch(OTTO_N_SESSIONS, n_aids=OTTO_N_AIDS, seed=42, device=gpu_device)
+    kinds = ('click_weighted', 'cart_weighted', 'click_click')
+    ts_min, ts_max = int(d['ts'].min()), int(d['ts'].max())
+    k = 20
+
+    def run(chunks, partition):
+        b = CovisBuilder(OTTO_N_AIDS, kinds=kinds, ts_min=ts_min, ts_max=ts_max, device=gpu_device)
+        b.set_option('partition', partition)
+        S = OTTO_N_SESSIONS
+        cuts = [S * c // chunks for c in range(chunks + 1)]
+        for c in range(chunks):
+            lo, hi = cuts[c], cuts[c + 1]
+            e0, e1 = int(d['sess_off'][lo]), int(d['sess_off'][hi])
+            b.feed(d['aid'][e0:e1], d['ts'][e0:e1], d['type'][e0:e1], (d['sess_off'][lo:hi + 1] - e0).contiguous())
+        out = b.finalize(k=k)
+        st = b.stats()
+        b.close()
+        return out, st
+
+    out1, st1 = run(1, 1)
+    out2, st2 = run(7, 0)
+    assert st1['pairs'] == st2['pairs'] > 1_000_000_000 and st1['runs'] == st2['runs']
+    assert st1['items_l'] > 0 and st1['retries'] == 0
+    for kind in kinds:
+        for a_, b_ in zip(out1[kind], out2[kind]):
+            nz = torch.arange(k, device=gpu_device)[None, :] < out1[kind][2][:, None]
+            if a_.dim() == 2:
+                assert torch.equal(a_[nz], b_[nz]), kind
+            else:
+                assert torch.equal(a_, b_), kind
+    for kind in kinds:
+        y, w, n = out1[kind]
+        valid = torch.arange(k, device=gpu_device)[None, :] < n[:, None]
+        assert int(n.max()) <= k and int((n > 0).sum()) > 1_000_000
+        both = valid[:, 1:] & valid[:, :-1]
+        w0, w1, y0, y1 = w[:, :-1], w[:, 1:], y[:, :-1], y[:, 1:]
+        assert bool(((w0 > w1) | ((w0 == w1) & (y0 < y1)))[both].all()), f'{kind}: rows not sorted by (W desc, aid_y asc)'
+        xs = torch.arange(OTTO_N_AIDS, device=gpu_device, dtype=torch.int32)[:, None]
+        assert not bool(((y == xs) & valid).any()), 'aid_x listed as its own neighbour'
+        assert bool((w[valid] % 65536 == 0).all()) and bool((w[valid] > 0).all())
+    # cart_weighted (1,9,6) dominates click_weighted (1,6,3) pair by pair, so its best weight per aid is >= too
+    some = out1['click_weighted'][2] > 0          # entries beyond n are unspecified
+    assert bool((out1['cart_weighted'][1][:, 0] >= out1['click_weighted'][1][:, 0])[some].all())
+    # symmetry of click_click on a sample of aids
+    y, w, n = out1['click_click']
+    sample = torch.randperm(OTTO_N_AIDS, device=gpu_device)[:200_000]
+    ys, ws, ns = y[sample].long(), w[sample], n[sample]
+    valid = torch.arange(k, device=gpu_device)[None, :] < ns[:, None]
+    ys = torch.where(valid, ys, torch.zeros_like(ys))                 # entries beyond n are unspecified
+    back_y, back_w, back_n = y[ys], w[ys], n[ys]                      # [m, k, k] lists of the neighbours
+    hit = (back_y == sample[:, None, None].to(torch.int32)) & (torch.arange(k, device=gpu_device)[None, None, :] < back_n[..., None])
+    has = hit.any(-1) & valid
+    wb = (back_w * hit).sum(-1)
+    assert int(has.sum()) > 10_000, 'too few mutual pairs in the sample to test symmetry'
+    assert bool((wb[has] == ws[has]).all()), 'click_click is not symmetric'
