@@ -224,6 +224,7 @@ def test_full_size_step_and_scoring_against_torch_on_gpu(gpu_device):
     eng = MFEngine(n1, n2, d, B, device=gpu_device)
     loss = torch.zeros(2, device=gpu_device)
     pop = torch.rand(n2, device=gpu_device, generator=g) ** 8          # skewed aid popularity -> duplicates in the batch
+    untouched = torch.ones(n2, dtype=torch.bool, device=gpu_device)
     for step in (1, 2):
         i1 = torch.randint(0, n1, (B,), device=gpu_device, generator=g)
         i2 = torch.multinomial(pop, B, replacement=True, generator=g)
@@ -236,13 +237,12 @@ def test_full_size_step_and_scoring_against_torch_on_gpu(gpu_device):
         opt.step()
         assert abs(loss[step - 1].item() - l.item()) <= RTOL * abs(l.item())
         rows2 = torch.unique(i2)
+        untouched[rows2] = False
         a, b = E2[rows2], ref2.weight.detach()[rows2]
         assert torch.linalg.norm(a - b) <= RTOL * torch.linalg.norm(b)
         rows1 = torch.unique(i1)[:50_000]
         a, b = E1[rows1], ref1.weight.detach()[rows1]
         assert torch.linalg.norm(a - b) <= RTOL * torch.linalg.norm(b)
-    untouched = torch.ones(n2, dtype=torch.bool, device=gpu_device)
-    untouched[rows2] = False
     assert torch.equal(E2[untouched][:1000], ref2.weight.detach()[untouched][:1000])      # rows outside the batch never move
     del ref1, ref2, opt, E1, m1, v1, eng
     torch.cuda.empty_cache()
