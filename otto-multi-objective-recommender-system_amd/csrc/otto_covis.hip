@@ -433,7 +433,9 @@ constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
 constexpr int MAX_K = 32;
 constexpr int MAX_KINDS = 4;
 constexpr int PK = 3;                    // kinds reduced per pass over the records
-constexpr int PART_CHUNK_RUNS = 1024;   // runs per partition-pass work item
+constexpr int PART_CHUNK_RUNS = 256;    // runs per partition-pass work item (<= 256 * 31 records: fits the LDS stage)
+constexpr int PART_STAGE = 8192;        // records staged in LDS per chunk
+constexpr int PART_STAGE_LOG2R = 10;    // staged (coalesced) scatter up to 1024 partitions, direct scatter above
 constexpr int PART_LDS_LOG2R = 12;      // partitions whose histogram / cursors fit LDS
 
 struct ReduceArgs {
@@ -723,14 +725,17 @@ struct PartArgs {
     uint32_t* prec;
     uint32_t* ptw;
     uint32_t l_cap;
+    int window_max;                // largest window (records per run <= window_max - 1)
 };
 
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
     constexpr int NW = 4;
-    constexpr int RL = 1 << PART_LDS_LOG2R;
-    __shared__ uint32_t s_cnt[RL];
-    __shared__ uint32_t s_base[SCATTER ? RL : 1];   // bucket cursor start relative to the aid's first bucket
+    constexpr int RL = 1 << (SCATTER ? PART_STAGE_LOG2R : PART_LDS_LOG2R);
+    __shared__ uint32_t s_cnt[RL];                     // histogram, then staging cursors
+    __shared__ uint32_t s_delta[SCATTER ? RL : 1];     // (global bucket position - position in the stage) per partition
+    __shared__ uint32_t s_stage[SCATTER ? PART_STAGE : 1];
+    __shared__ uint32_t s_scan[256 / 64 + 1];
     const int wid = threadIdx.x >> 6;
     for (uint32_t ci = blockIdx.x; ci < a.n_chunks; ci += gridDim.x) {
         const uint64_t ch = a.chunks[ci];
@@ -744,8 +749,10 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
         const uint64_t rb = a.run_start[x] + c * PART_CHUNK_RUNS;
         uint64_t re = rb + PART_CHUNK_RUNS;
         if (re > a.run_start[x + 1]) re = a.run_start[x + 1];
-        if (lgR > PART_LDS_LOG2R || (a.cnt64[x] & CNT_REC_MASK) >= (1ull << 32)) {
-            // more partitions than LDS counters: global atomics per record (giant aids only)
+        const bool direct = lgR > (SCATTER ? PART_STAGE_LOG2R : PART_LDS_LOG2R) || (a.cnt64[x] & CNT_REC_MASK) >= (1ull << 32) ||
+                            (SCATTER && a.ptw != nullptr) || (SCATTER && a.window_max * PART_CHUNK_RUNS > PART_STAGE);
+        if (direct) {
+            // no LDS staging (giant aids, or the time channel travels along): global cursor per record
             for_each_record<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t slot) {
                 const uint64_t g = g0 + ((rec_hash(rc) >> pshift) & pmask);
                 if (!SCATTER) atomicAdd(&a.pcount[g], 1u);
@@ -769,18 +776,40 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
                 if (n) atomicAdd(&a.pcount[g0 + p], n);
             }
         } else {
-            for (uint32_t p = threadIdx.x; p < R; p += 256) {
-                const uint32_t n = s_cnt[p];
-                if (n) s_base[p] = (uint32_t)(a.pstart[g0 + p] - x_base) + atomicAdd(&a.pcursor[g0 + p], n);
-                s_cnt[p] = 0;
+            // exclusive scan of the chunk's per-partition counts -> positions in the LDS stage; one global
+            // cursor bump per (chunk, partition) reserves the matching bucket range
+            constexpr int PPT = RL / 256;                  // partitions per thread
+            uint32_t cnt[PPT], tsum = 0;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const uint32_t p = threadIdx.x * PPT + q;
+                cnt[q] = p < R ? s_cnt[p] : 0u;
+                tsum += cnt[q];
+            }
+            uint32_t total;
+            uint32_t off = block_excl_scan<uint32_t, 256>(tsum, s_scan, &total);
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const uint32_t p = threadIdx.x * PPT + q;
+                if (p < R) {
+                    uint32_t gpos = 0;
+                    if (cnt[q]) gpos = (uint32_t)(a.pstart[g0 + p] - x_base) + atomicAdd(&a.pcursor[g0 + p], cnt[q]);
+                    s_delta[p] = gpos - off;
+                    s_cnt[p] = off;
+                    off += cnt[q];
+                }
             }
             __syncthreads();
-            for_each_record<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t slot) {
+            for_each_record<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t) {
                 const uint32_t p = (rec_hash(rc) >> pshift) & pmask;
-                const uint64_t pos = x_base + s_base[p] + atomicAdd(&s_cnt[p], 1u);
-                a.prec[pos] = rc;
-                if (a.ptw) a.ptw[pos] = a.tw[slot];
+                s_stage[atomicAdd(&s_cnt[p], 1u)] = rc;
             });
+            __syncthreads();
+            // the stage is grouped by partition: consecutive threads write consecutive bucket addresses
+            for (uint32_t i = threadIdx.x; i < total; i += 256) {
+                const uint32_t rc = s_stage[i];
+                a.prec[x_base + (uint32_t)(s_delta[(rec_hash(rc) >> pshift) & pmask] + i)] = rc;
+            }
         }
         __syncthreads();
     }
@@ -1568,7 +1597,7 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
             PartArgs pa{c->chunks.as<uint64_t>(), (uint32_t)c->n_chunks, c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(),
                         c->run_start.as<uint64_t>(), c->sorted_desc.as<uint64_t>(), c->rec.as<uint32_t>(), c->tw.as<uint32_t>(),
                         c->litem_start.as<uint64_t>(), c->pcount.as<uint32_t>(), c->pcursor.as<uint32_t>(),
-                        c->pstart.as<uint64_t>(), c->prec.as<uint32_t>(), time ? c->ptw.as<uint32_t>() : nullptr, c->l_cap};
+                        c->pstart.as<uint64_t>(), c->prec.as<uint32_t>(), time ? c->ptw.as<uint32_t>() : nullptr, c->l_cap, c->p.window};
             const uint32_t pgrid = (uint32_t)(c->n_chunks < 256u * 5u ? c->n_chunks : 256u * 5u);
             const uint32_t cgrid = (uint32_t)(c->n_chunks < 256u * 8u ? c->n_chunks : 256u * 8u);
             k_partition<false><<<cgrid, 256, 0, s>>>(pa);
