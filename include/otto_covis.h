@@ -89,7 +89,8 @@ int otto_covis_reset(otto_covis_ctx* ctx);
 
 /*
  * K1 pair-expand over one chunk of sessions.  Events of session s are
- * d_aid/d_ts/d_type[d_sess_off[s] .. d_sess_off[s+1]) sorted by ts.  May be called
+ * d_aid/d_ts/d_type[d_sess_off[s] .. d_sess_off[s+1]) with ts NON-DECREASING inside a session (SPEC-COVIS 1;
+ * the gap-free window test relies on it).  May be called
  * several times (session chunks); records accumulate in the context.
  * Synchronises the stream once (to size the record buffers).
  */

@@ -135,26 +135,39 @@ constexpr uint32_t M_EMPTY = 0xFFFFFFFFu;
 constexpr int REC_AID_BITS = 26;
 constexpr uint32_t REC_AID_MASK = (1u << REC_AID_BITS) - 1;
 
-// window size classes: a window of n events runs on G = 8 / 16 / 32 lanes (8 / 4 / 2 windows per wave)
-__device__ __forceinline__ int win_class(int64_t len, int W) {
-    const int64_t n = len < W ? len : W;
-    return n < 2 ? -1 : (n <= 8 ? 0 : (n <= 16 ? 1 : 2));
-}
-struct WinClass {   // 1 if session i falls in size class `cls`
-    const int64_t* off;
-    int W;
-    int cls;
-    __device__ uint64_t operator()(int64_t i) const { return win_class(off[i + 1] - off[i], W) == cls ? 1ull : 0ull; }
-};
-// sess_list[class_base[c] + rank within class] = session index
-__global__ void k_fill_classes(const int64_t* off, int W, int64_t n_sess, const uint64_t* pos0, const uint64_t* pos1,
-                               const uint64_t* pos2, uint64_t base1, uint64_t base2, uint32_t* sess_list) {
+// window classes: size (n <= 8 / 16 / 32 events -> G = 8 / 16 / 32 lanes, 8 / 4 / 2 windows per wave) x
+// "gap-free" (time span of the whole window <= max_gap: every pair of distinct aids is valid, so the first
+// valid pair of (x, y) is (first x, first y) and neither the n^2 ds_min phase nor the M matrix is needed).
+constexpr int N_WIN_CLASSES = 6;
+__global__ void k_classify(const int64_t* off, const int32_t* ts, int W, int max_gap, int use_fast, int64_t n_sess,
+                           uint8_t* cls_out) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_sess) return;
-    const int c = win_class(off[s + 1] - off[s], W);
-    if (c == 0) sess_list[pos0[s]] = (uint32_t)s;
-    else if (c == 1) sess_list[base1 + pos1[s]] = (uint32_t)s;
-    else if (c == 2) sess_list[base2 + pos2[s]] = (uint32_t)s;
+    const int64_t lo = off[s], hi = off[s + 1];
+    int64_t n = hi - lo;
+    n = n < W ? n : W;
+    uint8_t c = 255;
+    if (n >= 2) {
+        c = n <= 8 ? 0 : (n <= 16 ? 1 : 2);
+        if (use_fast && (int64_t)ts[hi - 1] - (int64_t)ts[hi - n] <= (int64_t)max_gap) c += 3;
+    }
+    cls_out[s] = c;
+}
+struct WinClass {   // 1 if session i falls in class `cls`
+    const uint8_t* c;
+    int cls;
+    __device__ uint64_t operator()(int64_t i) const { return c[i] == cls ? 1ull : 0ull; }
+};
+struct ClassFill {
+    const uint64_t* pos[N_WIN_CLASSES];
+    uint64_t base[N_WIN_CLASSES];
+};
+// sess_list[base[c] + rank within class] = session index
+__global__ void k_fill_classes(const uint8_t* cls, int64_t n_sess, ClassFill f, uint32_t* sess_list) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_sess) return;
+    const int c = cls[s];
+    if (c < N_WIN_CLASSES) sess_list[f.base[c] + f.pos[c][s]] = (uint32_t)s;
 }
 
 struct ExpandArgs {
@@ -314,6 +327,88 @@ __global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
         if (g < n) {
             a.run_x[a.run_base + ebase + g] = aid;
             a.run_desc[a.run_base + ebase + g] = my_cnt ? (((a.rec_base + pbase + my_off) << 8) | my_cnt) : 0ull;
+        }
+        wave_lds_sync();
+    }
+}
+
+// Gap-free windows (no filter kinds): class ids, then per class row r the columns are simply the other class
+// representatives -- record = aid_y | type(first y) << 26, time extra of the first x. No M, no LDS atomics.
+template <int G, bool TIME>
+__global__ __launch_bounds__(256) void k_expand_fast(ExpandArgs a) {
+    constexpr int WPW = 64 / G;
+    __shared__ uint32_t s_aid[4][WPW][G];
+    const int wv = threadIdx.x >> 6;
+    const unsigned lane = lane_id();
+    const int grp = lane / G, g = lane % G;
+    const unsigned grp_shift = grp * G;
+    const uint64_t gmask = (1ull << G) - 1ull;
+    uint32_t* av = s_aid[wv][grp];
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t wave_stride = (int64_t)gridDim.x * 4;
+    for (int64_t w0 = wave_global * WPW; w0 < a.n_list; w0 += wave_stride * WPW) {
+        const int64_t li = w0 + grp;
+        int n = 0;
+        int64_t wstart = 0;
+        uint64_t pbase = 0, ebase = 0;
+        if (li < a.n_list) {
+            const int64_t s = a.sess_list[li];
+            const int64_t lo = a.sess_off[s], hi = a.sess_off[s + 1];
+            const int64_t len = hi - lo;
+            n = (int)(len < a.window ? len : a.window);
+            wstart = hi - n;
+            pbase = a.pair_base[s];
+            ebase = a.ev_base[s];
+        }
+        int nmax = 0;
+#pragma unroll
+        for (int q = 0; q < WPW; ++q) {
+            const int nq = __builtin_amdgcn_readlane(n, q * G);
+            nmax = nq > nmax ? nq : nmax;
+        }
+        const int nmax4 = (nmax + 3) & ~3;
+        uint32_t aid = 0xFFFFFFFFu, ty = 0, extra = 0;
+        if (g < n) {
+            aid = a.aid[wstart + g];
+            ty = a.type[wstart + g];
+            if (TIME) {
+                const int32_t t = a.ts[wstart + g];
+                extra = a.tspan > 0 ? (uint32_t)((uint64_t)(196608ull * (uint64_t)((int64_t)t - a.t0)) / (uint64_t)a.tspan) : 0u;
+            }
+        }
+        av[g] = aid;
+        wave_lds_sync();
+        int cls = g;
+        for (int j0 = nmax4 - 4; j0 >= 0; j0 -= 4) {
+            uint32_t ax[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ax[u] = av[(j0 + u) & (G - 1)];
+#pragma unroll
+            for (int u = 3; u >= 0; --u)
+                if (j0 + u < n && ax[u] == aid) cls = j0 + u;
+        }
+        const bool rep = g < n && cls == g;
+        const uint32_t repm = (uint32_t)((__ballot(rep) >> grp_shift) & gmask);     // class representatives of my window
+        const uint32_t d = __popc(repm);
+        const uint32_t below = __popc(repm & ((1u << g) - 1u));                      // representatives before me
+        const uint32_t rec_word = aid | (ty << REC_AID_BITS);
+        // row r (a representative) lists every other representative in position order: d - 1 records
+        for (int r = 0; r < nmax; ++r) {
+            const bool row = (repm >> r) & 1u;                // uniform inside the window
+            if (row && rep && g != r) {
+                const uint32_t rowrank = __popc(repm & ((1u << r) - 1u));
+                const uint32_t rank = below - (g > r ? 1u : 0u);
+                const uint64_t slot = a.rec_base + pbase + (uint64_t)rowrank * (d - 1) + rank;
+                a.rec[slot] = rec_word;
+                if (TIME) a.tw[slot] = (uint32_t)__shfl((int)extra, (int)(grp_shift + r), 64);
+            } else if (TIME) {
+                (void)__shfl((int)extra, (int)(grp_shift + r), 64);
+            }
+        }
+        if (g < n) {
+            a.run_x[a.run_base + ebase + g] = aid;
+            const bool has = rep && d > 1;
+            a.run_desc[a.run_base + ebase + g] = has ? (((a.rec_base + pbase + (uint64_t)below * (d - 1)) << 8) | (d - 1)) : 0ull;
         }
         wave_lds_sync();
     }
@@ -1313,7 +1408,8 @@ struct otto_covis_ctx {
     uint64_t run_used = 0;    // run slots
     int64_t sessions = 0;
     // chunk scratch
-    DevBuf pair_base, ev_base, partial, cls_pos[3], sess_list;
+    DevBuf pair_base, ev_base, partial, cls_pos[N_WIN_CLASSES], sess_list, cls_byte;
+    int fast_path = 1;
     // index
     bool index_valid = false;
     DevBuf cnt64, run_start, run_rank, sorted_desc, item_start, boost, flag, counters;
@@ -1372,7 +1468,8 @@ extern "C" int otto_covis_create(otto_covis_ctx** out, const otto_covis_params* 
 extern "C" void otto_covis_destroy(otto_covis_ctx* c) {
     if (!c) return;
     DevBuf* all[] = {&c->rec, &c->tw, &c->run_x, &c->run_desc, &c->pair_base, &c->ev_base, &c->partial, &c->cnt64,
-                     &c->cls_pos[0], &c->cls_pos[1], &c->cls_pos[2], &c->sess_list,
+                     &c->cls_pos[0], &c->cls_pos[1], &c->cls_pos[2], &c->cls_pos[3], &c->cls_pos[4], &c->cls_pos[5],
+                     &c->sess_list, &c->cls_byte,
                      &c->run_start, &c->run_rank, &c->sorted_desc, &c->item_start, &c->boost, &c->flag, &c->counters,
                      &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->exp_run_pos, &c->exp_rec_pos,
                      &c->litem_start, &c->chunks, &c->pcount, &c->pcursor, &c->pstart, &c->prec, &c->ptw};
@@ -1408,21 +1505,25 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
     OTTO_TRY(c->partial.ensure(scan_partial_bytes(n_sess > (int64_t)p.n_aids ? n_sess : (int64_t)p.n_aids), 0, s));
     OTTO_TRY(device_scan(WinPairs{d_sess_off, p.window}, n_sess, c->pair_base.as<uint64_t>(), c->partial.as<uint64_t>(), s));
     OTTO_TRY(device_scan(WinEvents{d_sess_off, p.window}, n_sess, c->ev_base.as<uint64_t>(), c->partial.as<uint64_t>(), s));
-    // size classes of the windows (<= 8 / <= 16 / <= 32 events): one session list, three segments
+    // window classes (3 sizes x gap-free or not): one session list, six segments
     OTTO_REQUIRE(n_sess < (1ll << 32), "more than 2^32 sessions in one chunk");
-    for (int cl = 0; cl < 3; ++cl) {
+    const int use_fast = p.n_filters == 0 && c->fast_path;
+    OTTO_TRY(c->cls_byte.ensure((size_t)n_sess, 0, s));
+    k_classify<<<(unsigned)((n_sess + 255) / 256), 256, 0, s>>>(d_sess_off, d_ts, p.window, p.max_gap, use_fast, n_sess,
+                                                                 c->cls_byte.as<uint8_t>());
+    OTTO_HIP(hipGetLastError());
+    for (int cl = 0; cl < N_WIN_CLASSES; ++cl) {
         OTTO_TRY(c->cls_pos[cl].ensure((size_t)(n_sess + 1) * 8, 0, s));
-        OTTO_TRY(device_scan(WinClass{d_sess_off, p.window, cl}, n_sess, c->cls_pos[cl].as<uint64_t>(), c->partial.as<uint64_t>(), s));
+        OTTO_TRY(device_scan(WinClass{c->cls_byte.as<uint8_t>(), cl}, n_sess, c->cls_pos[cl].as<uint64_t>(), c->partial.as<uint64_t>(), s));
     }
     tend(c, OTTO_COVIS_T_WINSCAN, s);
-    uint64_t totals[5];
+    uint64_t totals[2 + N_WIN_CLASSES];
     OTTO_HIP(hipMemcpyAsync(&totals[0], c->pair_base.as<uint64_t>() + n_sess, 8, hipMemcpyDeviceToHost, s));
     OTTO_HIP(hipMemcpyAsync(&totals[1], c->ev_base.as<uint64_t>() + n_sess, 8, hipMemcpyDeviceToHost, s));
-    for (int cl = 0; cl < 3; ++cl)
+    for (int cl = 0; cl < N_WIN_CLASSES; ++cl)
         OTTO_HIP(hipMemcpyAsync(&totals[2 + cl], c->cls_pos[cl].as<uint64_t>() + n_sess, 8, hipMemcpyDeviceToHost, s));
     OTTO_HIP(hipStreamSynchronize(s));
     const uint64_t n_slots = totals[0], n_ev = totals[1];
-    const uint64_t n_cls[3] = {totals[2], totals[3], totals[4]};
     OTTO_REQUIRE(c->rec_used + n_slots < (1ull << 55), "record slot space exhausted");
 
     OTTO_TRY(c->rec.ensure((size_t)(c->rec_used + n_slots) * 4, (size_t)c->rec_used * 4, s));
@@ -1432,9 +1533,14 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
     OTTO_TRY(c->sess_list.ensure((size_t)(n_sess + 1) * 4, 0, s));
 
     tbegin(c, OTTO_COVIS_T_EXPAND, s);
-    k_fill_classes<<<(unsigned)((n_sess + 255) / 256), 256, 0, s>>>(d_sess_off, p.window, n_sess, c->cls_pos[0].as<uint64_t>(),
-                                                                     c->cls_pos[1].as<uint64_t>(), c->cls_pos[2].as<uint64_t>(),
-                                                                     n_cls[0], n_cls[0] + n_cls[1], c->sess_list.as<uint32_t>());
+    ClassFill cf;
+    uint64_t lb = 0;
+    for (int cl = 0; cl < N_WIN_CLASSES; ++cl) {
+        cf.pos[cl] = c->cls_pos[cl].as<uint64_t>();
+        cf.base[cl] = lb;
+        lb += totals[2 + cl];
+    }
+    k_fill_classes<<<(unsigned)((n_sess + 255) / 256), 256, 0, s>>>(c->cls_byte.as<uint8_t>(), n_sess, cf, c->sess_list.as<uint32_t>());
     OTTO_HIP(hipGetLastError());
     ExpandArgs a;
     a.aid = d_aid; a.ts = d_ts; a.type = d_type; a.sess_off = d_sess_off;
@@ -1445,25 +1551,28 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
     a.window = p.window; a.max_gap = p.max_gap;
     a.t0 = p.ts_min; a.tspan = (int64_t)p.ts_max - (int64_t)p.ts_min;
     for (int f = 0; f < 4; ++f) a.fmask[f] = f < p.n_filters ? p.filter_mask[f] : 0u;
-    uint64_t lbase = 0;
-    for (int cl = 0; cl < 3; ++cl) {
-        a.sess_list = c->sess_list.as<uint32_t>() + lbase;
-        a.n_list = (int64_t)n_cls[cl];
-        lbase += n_cls[cl];
+    for (int cl = 0; cl < N_WIN_CLASSES; ++cl) {
+        a.sess_list = c->sess_list.as<uint32_t>() + cf.base[cl];
+        a.n_list = (int64_t)totals[2 + cl];
         if (a.n_list == 0) continue;
-        const int wpw = cl == 0 ? 8 : (cl == 1 ? 4 : 2);
+        const int size_cl = cl % 3;
+        const bool fast = cl >= 3;
+        const int wpw = size_cl == 0 ? 8 : (size_cl == 1 ? 4 : 2);
         const int64_t waves = (a.n_list + wpw - 1) / wpw;
         const int64_t blocks = (waves + 3) / 4;
         const int grid = (int)(blocks < 256 * 16 ? blocks : 256 * 16);
         const int variant = (p.want_time ? 2 : 0) | (p.n_filters > 0 ? 1 : 0);
 #define OTTO_EXPAND(G)                                                                   \
-        switch (variant) {                                                               \
+        if (fast) {                                                                      \
+            if (p.want_time) k_expand_fast<G, true><<<grid, 256, 0, s>>>(a);             \
+            else k_expand_fast<G, false><<<grid, 256, 0, s>>>(a);                        \
+        } else switch (variant) {                                                        \
             case 0: k_expand<G, false, false><<<grid, 256, 0, s>>>(a); break;            \
             case 1: k_expand<G, false, true><<<grid, 256, 0, s>>>(a); break;             \
             case 2: k_expand<G, true, false><<<grid, 256, 0, s>>>(a); break;             \
             default: k_expand<G, true, true><<<grid, 256, 0, s>>>(a); break;             \
         }
-        if (cl == 0) { OTTO_EXPAND(8) } else if (cl == 1) { OTTO_EXPAND(16) } else { OTTO_EXPAND(32) }
+        if (size_cl == 0) { OTTO_EXPAND(8) } else if (size_cl == 1) { OTTO_EXPAND(16) } else { OTTO_EXPAND(32) }
 #undef OTTO_EXPAND
         OTTO_HIP(hipGetLastError());
     }
@@ -1720,6 +1829,7 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
         return 0;
     }
     if (strcmp(name, "debug_skip") == 0) { c->debug_skip = (int)value; return 0; }   // timing diagnostics, results invalid
+    if (strcmp(name, "fast_path") == 0) { c->fast_path = value != 0; return 0; }   // gap-free window kernel on/off (A/B)
     if (strcmp(name, "partition") == 0) {
         // 1 (default): bucket heavy aids' records by hash partition once; 0: every partition re-reads
         // all of its aid's records and filters (round-1 baseline, kept for A/B measurements)

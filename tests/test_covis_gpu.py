@@ -278,8 +278,8 @@ def test_sharded_builder_two_ranks_on_one_gpu(gpu_device):
 def test_full_otto_scale_properties(gpu_device):
     """BASELINE.json configs[1] size (14,571,582 sessions, ~243 M events, 1,855,603 aids): too big for the
     oracle, so parity is asserted through size-independent properties:
-      * two different code paths agree bit for bit: one feed + partitioned heavy aids  vs  7 session chunks
-        + the filter/re-read path for heavy aids (option partition=0);
+      * two different code paths agree bit for bit: one feed + gap-free fast-path expand + partitioned heavy aids
+        vs  7 session chunks + general expand kernel only + the filter/re-read path for heavy aids;
       * every list is sorted by (W desc, aid_y asc), has no duplicate aid_y, never contains aid_x, n <= k;
       * `click_click` (symmetric mask, unit weight) is symmetric: if y is listed for x and x for y the weights match;
       * for type-weighted kinds W is a multiple of 65536 and cart_weighted >= click_weighted-implied bounds;
@@ -295,6 +295,7 @@ def test_full_otto_scale_properties(gpu_device):
     def run(chunks, partition):
         b = CovisBuilder(OTTO_N_AIDS, kinds=kinds, ts_min=ts_min, ts_max=ts_max, device=gpu_device)
         b.set_option('partition', partition)
+        b.set_option('fast_path', partition)      # second run also takes the general pair-expand kernel for every window
         S = OTTO_N_SESSIONS
         cuts = [S * c // chunks for c in range(chunks + 1)]
         for c in range(chunks):
