@@ -68,10 +68,27 @@ def algorithmic_bytes(st, k, nk):
     return out
 
 
-def roofline_obj(name, ms, nbytes):
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'round1', 'traffic_v1.json')
+
+
+def pmc_traffic(substrings, full_otto):
+    """HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py under rocprofv3 --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE, separate runs, calibrated: tools/pmc_summarize.py). They were taken on the full-OTTO workload,
+    so they are only attached when the bench runs that same workload; otherwise null."""
+    if not full_otto or not os.path.exists(TRAFFIC_FILE):
+        return None
+    try:
+        kernels = json.load(open(TRAFFIC_FILE))['kernels']
+    except Exception:
+        return None
+    tot = sum(v['traffic_bytes_per_launch'] for k, v in kernels.items() if any(sub in k for sub in substrings))
+    return int(tot) if tot else None
+
+
+def roofline_obj(name, ms, nbytes, traffic=None):
     gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     return {'kernel': name, 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'avg_ms': round(ms, 4), 'algorithmic_bytes': int(nbytes)}
+            'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'avg_ms': round(ms, 4), 'algorithmic_bytes': int(nbytes)}
 
 
 def cpu_baseline(dev_data, n_sessions, k):
@@ -222,8 +239,12 @@ def main():
         ab = algorithmic_bytes(st_k, a.k, nk)
         cand = {n: kernel_ms.get(n, 0.0) for n in ('expand', 'index', 'partition', 'reduce_s', 'reduce_m', 'reduce_l')}
         dom = max(cand, key=cand.get)
-        knames = {'expand': 'k_expand<G,false,false> (G = 8, 16, 32 size-class launches + k_fill_classes)',
-                  'reduce_s': 'k_reduce<9,64,0>', 'reduce_m': 'k_reduce<12,256,0>', 'reduce_l': 'k_reduce<13,1024,0>',
+        full_otto = world == 1 and a.sessions == 14_571_582 and a.k == 20
+        ksub = {'expand': ('k_expand', 'k_fill_classes'), 'index': ('k_hist_runs', 'k_scatter_runs'), 'partition': ('k_partition',),
+                'reduce_s': ('k_reduce<9,',), 'reduce_m': ('k_reduce<12,',), 'reduce_l': ('k_reduce<13,',)}
+        knames = {'expand': 'k_expand<G,..> + k_expand_fast<G,..> (G = 8, 16, 32; general and gap-free windows) + k_fill_classes',
+                  'reduce_s': 'k_reduce<9, 64, 0, true, 5, 8>', 'reduce_m': 'k_reduce<12, 256, 0, true, 4, 4>',
+                  'reduce_l': 'k_reduce<13, 1024, 0, false, 4, 2>',
                   'partition': 'k_partition<false> + k_partition<true>', 'index': 'k_hist_runs + k_scatter_runs + scans'}
         result = {
             'metric': 'aid-pairs/sec covisitation build',
@@ -244,8 +265,8 @@ def main():
                 'pairs_total': int(pairs), 'kinds': list(BENCH_KINDS), 'k': a.k,
                 'parallelism': 'single GPU' if world == 1 else f'session-chunk x{world}, RCCL all-to-all-v of expanded runs by aid_x owner',
             },
-            'roofline': roofline_obj(knames[dom], cand[dom], ab[dom]),
-            'roofline_expand': roofline_obj(knames['expand'], cand['expand'], ab['expand']),
+            'roofline': roofline_obj(knames[dom], cand[dom], ab[dom], pmc_traffic(ksub[dom], full_otto)),
+            'roofline_expand': roofline_obj(knames['expand'], cand['expand'], ab['expand'], pmc_traffic(ksub['expand'], full_otto)),
             'kernel_ms': {k_: round(v, 3) for k_, v in kernel_ms.items()},
             'stats': st,
         }
@@ -258,7 +279,8 @@ def main():
         if bench_mf is not None:
             del builder, eng, out
             torch.cuda.empty_cache()
-            mf = bench_mf.run(a, dev, rank, world, mf_cpu_baseline if (rank == 0 and world == 1 and a.cpu_sessions > 0) else None)
+            mf = bench_mf.run(a, dev, rank, world, mf_cpu_baseline if (rank == 0 and world == 1 and a.cpu_sessions > 0) else None,
+                              (lambda subs: pmc_traffic(subs, world == 1 and a.sessions == 14_571_582)))
             if rank == 0:
                 result['mf'] = mf
     if rank == 0 and world == 1 and a.cpu_sessions > 0:

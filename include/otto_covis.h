@@ -150,6 +150,10 @@ enum {
 };
 int otto_covis_timings(otto_covis_ctx* ctx, float* out_ms /* [OTTO_COVIS_T_COUNT] */);
 
+/* PMC calibration helper: streams n_u32 * 4 bytes with one 4-byte access per lane (write != 0: stores, else loads),
+ * the access shape of the covisitation kernels, so FETCH_SIZE / WRITE_SIZE can be scaled to bytes (tools/pmc_traffic.py). */
+int otto_debug_calibrate(uint32_t* d_buf, int64_t n_u32, int32_t write, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,7 @@ SIGNATURES = {
     'otto_covis_import_runs': (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     'otto_covis_copy_records': (_i32, [_vp, _vp, _vp, _vp, _vp]),
     'otto_covis_timings': (_i32, [_vp, C.POINTER(C.c_float)]),
+    'otto_debug_calibrate': (_i32, [_vp, _i64, _i32, _vp]),
     # include/otto_mf.h
     'otto_mf_create': (_i32, [C.POINTER(_vp), _i64, _i64, _i32, _i64, _i32]),
     'otto_mf_destroy': (None, [_vp]),

@@ -13,7 +13,7 @@ SYNC_EVERY = 4
 HBM_PEAK_GBS = 8000.0
 
 
-def run(a, dev, rank, world, cpu_baseline_fn=None):
+def run(a, dev, rank, world, cpu_baseline_fn=None, traffic_fn=None):
     import torch
     import torch.distributed as dist
     from ..synth import generate_sessions_torch, OTTO_N_AIDS, OTTO_N_SESSIONS
@@ -87,7 +87,9 @@ def run(a, dev, rank, world, cpu_baseline_fn=None):
                    'rows_per_gpu': rows, 'factors': d,
                    'parallelism': 'single GPU' if world == 1 else f'data-parallel x{world}: user rows private, item-table deltas all-reduced (RCCL) every {SYNC_EVERY} launches'},
         'roofline': {'kernel': 'k_bpr_hogwild', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'avg_ms': round(launch_ms, 4),
+                     'frac': round(gbs / HBM_PEAK_GBS, 4),
+                     'traffic': traffic_fn(('k_bpr_hogwild',)) if (traffic_fn and d == 64 and rows >= ROWS_PER_LAUNCH) else None,
+                     'avg_ms': round(launch_ms, 4),
                      'algorithmic_bytes': int(per_triplet * (rows / n_launch))},
         'mean_loss_first_epoch': round(first_loss, 5), 'mean_loss_last_epoch': round(last_loss, 5),
     }
