@@ -129,6 +129,15 @@ int otto_covis_export_runs(otto_covis_ctx* ctx, uint32_t x_lo, uint32_t x_hi, ui
 int otto_covis_import_runs(otto_covis_ctx* ctx, const uint32_t* d_hdr, int64_t n_runs, const uint32_t* d_rec,
                            const uint32_t* d_tw, int64_t n_recs, void* stream);
 
+/* The same exchange in two passes over the runs for ALL owners at once: owner o holds aid_x in
+ * [h_bounds[o], h_bounds[o+1]) (host array of n_owners+1 cut points, first/last treated as 0 / +inf).
+ * plan: per-owner run and record counts (synchronises the stream); fill: every owner's piece, owner-major, in ONE
+ * hdr / rec (/ tw) buffer -- directly the send buffer of an all-to-all-v with the planned counts as split sizes. */
+int otto_covis_export_plan(otto_covis_ctx* ctx, int n_owners, const uint32_t* h_bounds, int64_t* h_n_runs,
+                           int64_t* h_n_recs, void* stream);
+int otto_covis_export_fill(otto_covis_ctx* ctx, int n_owners, const uint32_t* h_bounds, uint32_t* d_hdr, uint32_t* d_rec,
+                           uint32_t* d_tw, void* stream);
+
 /* Test hook: copy the raw K1 output to HOST buffers (any pointer may be NULL).
  * h_rec/h_tw: [PAIR_SLOTS] uint32, h_run_x: [TAIL_EVENTS] uint32, h_run_desc: [TAIL_EVENTS] uint64
  * (desc = slot_offset << 8 | len). rec = aid_y | type_y << 26 | filter_bits << 28. */

@@ -18,40 +18,48 @@ def owner_bounds(n_aids, world):
     return [int(round(i * n_aids / world)) for i in range(world + 1)]
 
 
-def exchange_runs(export_fn, import_fn, bounds, group=None, want_time=False, stage_device=None):
-    """Route runs to their aid_x owners.
+def exchange_runs(export_fn, import_fn, bounds, group=None, want_time=False, stage_device=None, export_all_fn=None):
+    """Route runs to their aid_x owners with one all-to-all-v per array.
 
-    ``stage_device`` (e.g. ``'cpu'`` with a gloo group): move the pieces there for the collectives and
-    back afterwards -- used to rehearse the multi-rank path on a single GPU; with nccl leave it None.
-
-    ``export_fn(lo, hi) -> (hdr int32 [n,2], rec int32 [m], tw int32 [m] | None)`` on the local
-    engine, ``import_fn(hdr, rec, tw)`` on the owner engine.  Works on any tensor device the
-    process group supports (nccl: device tensors; gloo: CPU tensors in the tests).
+    ``export_all_fn(bounds) -> (hdr [n,2], rec, tw|None, runs_per_owner, recs_per_owner)`` (engine.export_all: every
+    owner's piece already owner-major in one buffer) or, per owner, ``export_fn(lo, hi) -> (hdr, rec, tw|None)``;
+    ``import_fn(hdr, rec, tw)`` on the owner engine.  ``stage_device`` (e.g. ``'cpu'`` with a gloo group): move the
+    buffers there for the collectives and back -- used to rehearse the multi-rank path on a single GPU and in the
+    CPU tests; with nccl (= RCCL over xGMI) leave it None.
     Returns (runs_sent, recs_sent, runs_received, recs_received).
     """
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    pieces = [export_fn(bounds[r], bounds[r + 1]) for r in range(world)]
-    home = pieces[0][0].device
+    if export_all_fn is not None:
+        hdr_s, rec_s, tw_s, runs, recs = export_all_fn(bounds)
+    else:
+        pieces = [export_fn(bounds[r], bounds[r + 1]) for r in range(world)]
+        runs = [p[0].shape[0] for p in pieces]
+        recs = [p[1].numel() for p in pieces]
+        hdr_s = torch.cat([p[0].reshape(-1, 2) for p in pieces])
+        rec_s = torch.cat([p[1] for p in pieces])
+        tw_s = torch.cat([p[2] for p in pieces]) if want_time else None
+    home = hdr_s.device
     if stage_device is not None:
-        pieces = [tuple(None if t is None else t.to(stage_device) for t in p) for p in pieces]
-    dev = pieces[0][0].device
-    send_counts = torch.tensor([[p[0].shape[0], p[1].numel()] for p in pieces], dtype=torch.int64, device=dev)
+        hdr_s, rec_s = hdr_s.to(stage_device), rec_s.to(stage_device)
+        tw_s = None if tw_s is None else tw_s.to(stage_device)
+    dev = hdr_s.device
+    send_counts = torch.tensor([runs, recs], dtype=torch.int64, device=dev).t().contiguous()     # [world, 2]
     recv_counts = torch.empty_like(send_counts)
     dist.all_to_all_single(recv_counts, send_counts, group=group)
     sc = send_counts.cpu().numpy()
     rc = recv_counts.cpu().numpy()
 
-    def a2a(chunks, per_item, s_cnt, r_cnt):
-        send = torch.cat([c.reshape(-1) for c in chunks]) if chunks else torch.empty(0, dtype=torch.int32, device=dev)
+    def a2a(send, per_item, s_cnt, r_cnt):
         recv = torch.empty(int(r_cnt.sum()) * per_item, dtype=torch.int32, device=dev)
-        dist.all_to_all_single(recv, send, [int(v) * per_item for v in r_cnt], [int(v) * per_item for v in s_cnt], group=group)
+        dist.all_to_all_single(recv, send.reshape(-1), [int(v) * per_item for v in r_cnt], [int(v) * per_item for v in s_cnt],
+                               group=group)
         return recv
 
-    hdr = a2a([p[0] for p in pieces], 2, sc[:, 0], rc[:, 0]).reshape(-1, 2)
-    rec = a2a([p[1] for p in pieces], 1, sc[:, 1], rc[:, 1])
-    tw = a2a([p[2] for p in pieces], 1, sc[:, 1], rc[:, 1]) if want_time else None
+    hdr = a2a(hdr_s, 2, sc[:, 0], rc[:, 0]).reshape(-1, 2)
+    rec = a2a(rec_s, 1, sc[:, 1], rc[:, 1])
+    tw = a2a(tw_s, 1, sc[:, 1], rc[:, 1]) if want_time else None
     if stage_device is not None:
         hdr, rec, tw = hdr.to(home), rec.to(home), None if tw is None else tw.to(home)
     import_fn(hdr.contiguous(), rec.contiguous(), tw)
@@ -94,5 +102,5 @@ class ShardedCovisBuilder:
 
     def finalize(self, k=20, out=None):
         self.last_exchange = exchange_runs(self.local.export_runs, self.owner.import_runs, self.bounds, self.group,
-                                           self.local.want_time, self.stage_device)
+                                           self.local.want_time, self.stage_device, export_all_fn=self.local.export_all)
         return self.owner.finalize(k=k, out=out)

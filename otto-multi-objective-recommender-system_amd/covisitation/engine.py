@@ -148,6 +148,24 @@ class CovisBuilder:
                                                         self._stream()), 'otto_covis_export_runs')
         return hdr, rec, tw
 
+    def export_all(self, bounds):
+        """Every owner's piece in ONE owner-major buffer (owner o = aid_x in [bounds[o], bounds[o+1])): returns
+        (hdr int32 [n_runs,2], rec int32 [n_recs], tw|None, runs_per_owner, recs_per_owner) -- the send buffers and
+        split sizes of the all-to-all-v."""
+        t = self.torch
+        W = len(bounds) - 1
+        hb = (C.c_uint32 * (W + 1))(*[int(b) for b in bounds])
+        nr, nc = (C.c_int64 * W)(), (C.c_int64 * W)()
+        with t.cuda.device(self.device):
+            _lib.check(self._lib.otto_covis_export_plan(self._ctx, W, hb, nr, nc, self._stream()), 'otto_covis_export_plan')
+            runs, recs = [int(v) for v in nr], [int(v) for v in nc]
+            hdr = t.empty((sum(runs), 2), dtype=t.int32, device=self.device)
+            rec = t.empty(sum(recs), dtype=t.int32, device=self.device)
+            tw = t.empty(sum(recs), dtype=t.int32, device=self.device) if self.want_time else None
+            _lib.check(self._lib.otto_covis_export_fill(self._ctx, W, hb, _ptr(hdr), _ptr(rec), _ptr(tw), self._stream()),
+                       'otto_covis_export_fill')
+        return hdr, rec, tw, runs, recs
+
     def import_runs(self, hdr, rec, tw=None):
         t = self.torch
         with t.cuda.device(self.device):

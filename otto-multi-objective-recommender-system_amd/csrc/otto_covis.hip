@@ -1380,6 +1380,96 @@ __global__ void k_export(const uint32_t* run_x, const uint64_t* run_desc, int64_
     }
 }
 
+// ---- one-pass export of every owner's piece (owner-major in ONE buffer, ready to be the all-to-all send buffer) ----
+constexpr int MAX_OWNERS = 64;
+struct OwnerArgs {
+    const uint32_t* run_x;
+    const uint64_t* run_desc;
+    int64_t n_slots;
+    int n_owners;
+    uint32_t bounds[MAX_OWNERS + 1];     // owner o holds aid_x in [bounds[o], bounds[o+1])
+    uint64_t run_base[MAX_OWNERS];       // fill: first run / record of owner o inside the output buffers
+    uint64_t rec_base[MAX_OWNERS];
+    unsigned long long* totals;          // [MAX_OWNERS] runs << 36 | records per owner (plan: totals; fill: running cursor).
+                                         // ONE word so a block's run range and record range are reserved by one atomic
+    const uint32_t* rec;
+    const uint32_t* tw;
+    uint32_t* o_hdr;
+    uint32_t* o_rec;
+    uint32_t* o_tw;
+};
+
+__device__ __forceinline__ int owner_of(const OwnerArgs& a, uint32_t x) {
+    int o = 0;
+    while (o + 1 < a.n_owners && x >= a.bounds[o + 1]) ++o;
+    return o;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_export_all(OwnerArgs a) {
+    __shared__ unsigned long long s_rr[MAX_OWNERS];      // runs << 32 | records of this block per owner: ONE atomic hands a
+                                                         // run its rank AND its record offset, so both orders agree
+    __shared__ unsigned long long s_rbase[MAX_OWNERS], s_cbase[MAX_OWNERS];
+    __shared__ uint64_t s_src[256], s_dst[256];
+    __shared__ uint32_t s_len[256];
+    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < a.n_slots; b0 += (int64_t)gridDim.x * 256) {
+        if (threadIdx.x < MAX_OWNERS) s_rr[threadIdx.x] = 0;
+        __syncthreads();
+        const int64_t i = b0 + threadIdx.x;
+        uint64_t d = 0;
+        uint32_t x = 0, len = 0;
+        int o = 0;
+        uint32_t my_run = 0, my_rec = 0;
+        if (i < a.n_slots) {
+            d = a.run_desc[i];
+            len = (uint32_t)(d & 0xFFull);
+            if (len) {
+                x = a.run_x[i];
+                o = owner_of(a, x);
+                const unsigned long long old = atomicAdd(&s_rr[o], (1ull << 32) | len);
+                my_run = (uint32_t)(old >> 32);               // rank of this run / offset of its records in the block's share
+                my_rec = (uint32_t)old;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < a.n_owners) {
+            const unsigned long long r = s_rr[threadIdx.x] >> 32, c = s_rr[threadIdx.x] & 0xFFFFFFFFull;
+            unsigned long long rb = 0, cb = 0;
+            if (r) {
+                const unsigned long long old = atomicAdd(&a.totals[threadIdx.x], (r << CNT_REC_BITS) | c);
+                rb = old >> CNT_REC_BITS;
+                cb = old & CNT_REC_MASK;
+            }
+            s_rbase[threadIdx.x] = rb;
+            s_cbase[threadIdx.x] = cb;
+        }
+        if (FILL) {
+            __syncthreads();
+            s_len[threadIdx.x] = 0;
+            if (len) {
+                const uint64_t rp = a.run_base[o] + s_rbase[o] + my_run;
+                const uint64_t cp = a.rec_base[o] + s_cbase[o] + my_rec;
+                a.o_hdr[2 * rp] = x;
+                a.o_hdr[2 * rp + 1] = len;
+                s_src[threadIdx.x] = d >> 8;
+                s_dst[threadIdx.x] = cp;
+                s_len[threadIdx.x] = len;
+            }
+            __syncthreads();
+            // copy the records: one 32-lane half-wave per run -> contiguous reads and writes
+            const int hw = threadIdx.x >> 5, l = threadIdx.x & 31;
+            for (int r = hw; r < 256; r += 8) {
+                const uint32_t ln = s_len[r];
+                if ((uint32_t)l < ln) {
+                    a.o_rec[s_dst[r] + l] = a.rec[s_src[r] + l];
+                    if (a.o_tw) a.o_tw[s_dst[r] + l] = a.tw[s_src[r] + l];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 struct HdrLen {
     const uint32_t* hdr;
     __device__ uint64_t operator()(int64_t i) const { return hdr[2 * i + 1]; }
@@ -1425,7 +1515,9 @@ struct otto_covis_ctx {
     int debug_skip = 0;
     // reduce scratch
     DevBuf part_y, part_w;
-    DevBuf exp_run_pos, exp_rec_pos;
+    DevBuf exp_run_pos, exp_rec_pos, exp_totals;
+    uint64_t exp_n_runs[64] = {0}, exp_n_recs[64] = {0};
+    int exp_planned = 0;
     int64_t retries = 0;
     uint32_t l_cap = L_CAP;
     hipEvent_t ev[2 * OTTO_COVIS_T_COUNT];
@@ -1471,7 +1563,7 @@ extern "C" void otto_covis_destroy(otto_covis_ctx* c) {
                      &c->cls_pos[0], &c->cls_pos[1], &c->cls_pos[2], &c->cls_pos[3], &c->cls_pos[4], &c->cls_pos[5],
                      &c->sess_list, &c->cls_byte,
                      &c->run_start, &c->run_rank, &c->sorted_desc, &c->item_start, &c->boost, &c->flag, &c->counters,
-                     &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->exp_run_pos, &c->exp_rec_pos,
+                     &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->exp_run_pos, &c->exp_rec_pos, &c->exp_totals,
                      &c->litem_start, &c->chunks, &c->pcount, &c->pcursor, &c->pstart, &c->prec, &c->ptw};
     for (DevBuf* b : all) b->release();
     if (c->ev_ok)
@@ -1938,6 +2030,76 @@ extern "C" int otto_covis_export_runs(otto_covis_ctx* c, uint32_t x_lo, uint32_t
     k_export<<<grid, 256, 0, s>>>(c->run_x.as<uint32_t>(), c->run_desc.as<uint64_t>(), n_slots, x_lo, x_hi,
                                   c->exp_run_pos.as<uint64_t>(), c->exp_rec_pos.as<uint64_t>(), c->rec.as<uint32_t>(),
                                   c->tw.as<uint32_t>(), d_hdr, d_rec, d_tw);
+    OTTO_HIP(hipGetLastError());
+    return 0;
+}
+
+static int owner_args(otto_covis_ctx* c, int n_owners, const uint32_t* h_bounds, OwnerArgs& a) {
+    OTTO_REQUIRE(c && h_bounds, "null argument");
+    OTTO_REQUIRE(n_owners >= 1 && n_owners <= MAX_OWNERS, "n_owners must be in [1, %d]", MAX_OWNERS);
+    for (int o = 0; o < n_owners; ++o) OTTO_REQUIRE(h_bounds[o] <= h_bounds[o + 1], "owner bounds must be non-decreasing");
+    memset(&a, 0, sizeof a);
+    a.run_x = c->run_x.as<uint32_t>();
+    a.run_desc = c->run_desc.as<uint64_t>();
+    a.n_slots = (int64_t)c->run_used;
+    a.n_owners = n_owners;
+    for (int o = 0; o <= n_owners; ++o) a.bounds[o] = h_bounds[o];
+    a.bounds[0] = 0;
+    a.bounds[n_owners] = 0xFFFFFFFFu;
+    return 0;
+}
+
+extern "C" int otto_covis_export_plan(otto_covis_ctx* c, int n_owners, const uint32_t* h_bounds, int64_t* h_n_runs,
+                                      int64_t* h_n_recs, void* stream) {
+    OTTO_REQUIRE(h_n_runs && h_n_recs, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    OwnerArgs a;
+    OTTO_TRY(owner_args(c, n_owners, h_bounds, a));
+    OTTO_REQUIRE(c->run_used < (1ull << (64 - CNT_REC_BITS)) && c->rec_used < (1ull << CNT_REC_BITS), "too many runs for the packed export cursor");
+    OTTO_TRY(c->exp_totals.ensure(2 * MAX_OWNERS * 8, 0, s));
+    OTTO_HIP(hipMemsetAsync(c->exp_totals.p, 0, 2 * MAX_OWNERS * 8, s));
+    a.totals = c->exp_totals.as<unsigned long long>();
+    if (a.n_slots) {
+        const int64_t nb = (a.n_slots + 255) / 256;
+        k_export_all<false><<<(unsigned)(nb < 256 * 16 ? nb : 256 * 16), 256, 0, s>>>(a);
+        OTTO_HIP(hipGetLastError());
+    }
+    unsigned long long t[MAX_OWNERS];
+    OTTO_HIP(hipMemcpyAsync(t, c->exp_totals.p, sizeof t, hipMemcpyDeviceToHost, s));
+    OTTO_HIP(hipStreamSynchronize(s));
+    for (int o = 0; o < n_owners; ++o) {
+        c->exp_n_runs[o] = t[o] >> CNT_REC_BITS;
+        c->exp_n_recs[o] = t[o] & CNT_REC_MASK;
+        h_n_runs[o] = (int64_t)c->exp_n_runs[o];
+        h_n_recs[o] = (int64_t)c->exp_n_recs[o];
+    }
+    c->exp_planned = n_owners;
+    return 0;
+}
+
+extern "C" int otto_covis_export_fill(otto_covis_ctx* c, int n_owners, const uint32_t* h_bounds, uint32_t* d_hdr,
+                                      uint32_t* d_rec, uint32_t* d_tw, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    OwnerArgs a;
+    OTTO_TRY(owner_args(c, n_owners, h_bounds, a));
+    OTTO_REQUIRE(c->exp_planned == n_owners, "call otto_covis_export_plan with the same owners first");
+    OTTO_REQUIRE(!d_tw || c->p.want_time, "no time channel to export");
+    uint64_t rb = 0, cb = 0;
+    for (int o = 0; o < n_owners; ++o) {
+        a.run_base[o] = rb;
+        a.rec_base[o] = cb;
+        rb += c->exp_n_runs[o];
+        cb += c->exp_n_recs[o];
+    }
+    if (rb == 0) return 0;
+    OTTO_REQUIRE(d_hdr && d_rec, "null export buffers");
+    OTTO_HIP(hipMemsetAsync(c->exp_totals.p, 0, 2 * MAX_OWNERS * 8, s));
+    a.totals = c->exp_totals.as<unsigned long long>();
+    a.rec = c->rec.as<uint32_t>();
+    a.tw = c->tw.as<uint32_t>();
+    a.o_hdr = d_hdr; a.o_rec = d_rec; a.o_tw = d_tw;
+    const int64_t nb = (a.n_slots + 255) / 256;
+    k_export_all<true><<<(unsigned)(nb < 256 * 16 ? nb : 256 * 16), 256, 0, s>>>(a);
     OTTO_HIP(hipGetLastError());
     return 0;
 }

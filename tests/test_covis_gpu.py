@@ -343,3 +343,31 @@ def test_full_otto_scale_properties(gpu_device):
     wb = (back_w * hit).sum(-1)
     assert int(has.sum()) > 10_000, 'too few mutual pairs in the sample to test symmetry'
     assert bool((wb[has] == ws[has]).all()), 'click_click is not symmetric'
+
+
+def test_export_all_equals_per_owner_export(gpu_device):
+    """The one-pass all-owner export (send buffer of the all-to-all-v) carries, per owner, exactly the runs the
+    per-range export does (as multisets: run order inside a piece is unspecified)."""
+    from otto_amd.covisitation.engine import CovisBuilder
+    ev = generate_sessions(2500, n_aids=800, seed=71)
+    b = CovisBuilder(ev.n_aids, kinds=cs.ALL_KINDS, ts_min=int(ev.ts.min()), ts_max=int(ev.ts.max()), device=gpu_device)
+    b.feed(*_to_dev(ev, gpu_device))
+    bounds = [0, 100, 100, 555, 800]            # includes an empty owner
+    hdr, rec, tw, runs, recs = b.export_all(bounds)
+    assert len(runs) == 4 and hdr.shape[0] == sum(runs) and rec.numel() == sum(recs) and runs[1] == 0
+    hdr, rec, tw = hdr.cpu().numpy(), rec.cpu().numpy(), tw.cpu().numpy()
+
+    def runs_of(h, r, t):
+        out, p = [], 0
+        for x, n in h.tolist():
+            out.append((x, tuple(r[p:p + n].tolist()), tuple(t[p:p + n].tolist())))
+            p += n
+        return sorted(out)
+    ro = co_ = 0
+    for o in range(4):
+        h1, r1, t1 = b.export_runs(bounds[o], bounds[o + 1])
+        want = runs_of(h1.cpu().numpy(), r1.cpu().numpy(), t1.cpu().numpy())
+        got = runs_of(hdr[ro:ro + runs[o]], rec[co_:co_ + recs[o]], tw[co_:co_ + recs[o]])
+        assert got == want, f'owner {o}'
+        ro += runs[o]
+        co_ += recs[o]
