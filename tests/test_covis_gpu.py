@@ -371,3 +371,35 @@ def test_export_all_equals_per_owner_export(gpu_device):
         assert got == want, f'owner {o}'
         ro += runs[o]
         co_ += recs[o]
+
+
+def test_randomized_small_configurations_vs_python_oracle(gpu_device):
+    """40 tiny adversarial streams (few aids -> heavy repeats and ties, equal timestamps, gaps right at the
+    threshold, window / k sweeps) against the literal pure-Python transcription of SPEC-COVIS."""
+    rng = np.random.default_rng(2024)
+    kinds = cs.ALL_KINDS
+    for trial in range(40):
+        n_aids = int(rng.choice([2, 3, 5, 9, 40]))
+        S = int(rng.integers(1, 60))
+        window = int(rng.choice([2, 3, 7, 16, 30, 32]))
+        gap = int(rng.choice([0, 1, 50, 86400]))
+        k = int(rng.choice([1, 2, 5, 20, 32]))
+        L = rng.integers(1, 45, S)
+        off = np.r_[0, np.cumsum(L)].astype(np.int64)
+        E = int(off[-1])
+        aid = rng.integers(0, n_aids, E).astype(np.uint32)
+        typ = rng.integers(0, 3, E).astype(np.uint8)
+        step = rng.choice([0, 0, 1, 25, 51, 90000], E)           # many equal timestamps, some gaps at / over the threshold
+        ts = np.zeros(E, dtype=np.int64)
+        for s in range(S):
+            seg = slice(int(off[s]), int(off[s + 1]))
+            ts[seg] = 1_660_000_000 + np.cumsum(step[seg])
+        ev = Events(aid=aid, ts=ts.astype(np.int32), type=typ, sess_off=off, n_aids=n_aids)
+        sp = co.CovisSpec(window=window, max_gap=gap, kinds=kinds)
+        want_pairs = co.covis_pairs_python(ev.aid, ev.ts, ev.type, ev.sess_off, sp)
+        want = {kd: co.topk_rows(*co.pairs_dict_to_arrays(want_pairs[kd]), k=k) for kd in kinds}
+        _, got = _build(ev, gpu_device, kinds=kinds, k=k, window=window, max_gap=gap, chunks=int(rng.integers(1, 4)))
+        try:
+            _assert_rows_equal(got, want, kinds)
+        except AssertionError as e:
+            raise AssertionError(f'trial {trial}: n_aids={n_aids} S={S} window={window} gap={gap} k={k}: {e}')

@@ -39,3 +39,17 @@ for r in range(a.reps):
     print('   stats', st, flush=True)
     print('   timings(ms)', {k: round(v, 3) for k, v in tm.items()}, flush=True)
 print('mem GB', torch.cuda.max_memory_allocated()/1e9)
+
+# export/import cost of the multi-GPU exchange for 8 owners (single-GPU measurement; RCCL time not included)
+import time as _t
+from otto_amd.covisitation.distributed import owner_bounds
+bounds = owner_bounds(OTTO_N_AIDS, 8)
+for r in range(2):
+    torch.cuda.synchronize(); t0 = _t.time()
+    hdr, rec, tw, runs, recs = b.export_all(bounds)
+    torch.cuda.synchronize(); t1 = _t.time()
+    owner = CovisBuilder(OTTO_N_AIDS, kinds=kinds, ts_min=0, ts_max=1, device=dev)
+    owner.import_runs(hdr, rec, tw)
+    torch.cuda.synchronize(); t2 = _t.time()
+    print(f'export_all(8 owners) {1e3*(t1-t0):.1f} ms  import {1e3*(t2-t1):.1f} ms  runs {sum(runs)} recs {sum(recs)}', flush=True)
+    del owner, hdr, rec
