@@ -1,0 +1,57 @@
+"""CPU ORACLE for the covisitation candidate lookup -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Restates, expression by expression, the per-session body of the reference's
+``src/ranker/covisitation_candidate_generation.py:108-157`` (the same loop, plus fastText neighbours, is
+``src/ranker/regular_candidate_generation.py:138-197`` and ``src/covisitation/inference.py:204-247``):
+
+    session_unique_aids               = list(dict.fromkeys(session_aids[::-1]))                       (:112)
+    session_unique_click_and_cart_aids = np.unique(aids[types <= 1]).tolist()                         (:116)
+    session_unique_cart_and_order_aids = np.unique(aids[types >= 1]).tolist()                         (:117)
+    <kind>_covisited_aids = list(itertools.chain(*[top_<kind>[aid] for aid in <source> if aid in top_<kind>]))   (:119-124)
+    covisited = concatenation of the recipe's lists                                                    (:127, :133, :138)
+    [(aid, count) for aid, count in Counter(covisited).most_common(100) if aid not in session_unique_aids]  (:128)
+
+``Counter.most_common`` is Python's own: ties keep first-insertion order -- the property the builder's rank order
+feeds.  PARITY: pinned by construction to the reference's expressions (the same stdlib calls); the
+reference holds no fixture for this loop (its inputs, the covisitation parquets, do not exist in the tree).
+"""
+from collections import Counter
+import itertools
+
+import numpy as np
+
+# recipes of covisitation_candidate_generation.py:127,133,138: (matrix kind, source list)
+CLICK_RECIPE = (('time_weighted', 'U'), ('click_weighted', 'CC'), ('cart_weighted', 'CC'), ('click_cart', 'CC'), ('cart_order', 'CC'))
+CART_RECIPE = (('time_weighted', 'U'), ('cart_weighted', 'CC'), ('cart_order', 'CC'))
+ORDER_RECIPE = CART_RECIPE
+
+
+def matrix_to_dict(y, n):
+    """Dense top-k arrays -> the dict the consumers build with covisitation_df_to_dict (covisitation/inference.py:19-35)."""
+    return {int(x): y[x, :n[x]].tolist() for x in np.flatnonzero(n > 0)}
+
+
+def session_candidates(session_aids, session_event_types, top, recipe, n_common=100):
+    session_aids = list(map(int, session_aids))
+    aids = np.array(session_aids)
+    types = np.array(session_event_types)
+    session_unique_aids = list(dict.fromkeys(session_aids[::-1]))
+    sources = {
+        'U': session_unique_aids,
+        'CC': np.unique(aids[types <= 1]).tolist(),
+        'CO': np.unique(aids[types >= 1]).tolist(),
+    }
+    covisited = []
+    for kind, src in recipe:
+        d = top[kind]
+        covisited += list(itertools.chain(*[d[aid] for aid in sources[src] if aid in d]))
+    out = [(aid, count) for aid, count in Counter(covisited).most_common(n_common) if aid not in session_unique_aids]
+    return [a for a, _ in out], [c for _, c in out]
+
+
+def all_candidates(aid, typ, sess_off, top, recipe, n_common=100):
+    res = []
+    for s in range(len(sess_off) - 1):
+        lo, hi = int(sess_off[s]), int(sess_off[s + 1])
+        res.append(session_candidates(aid[lo:hi], typ[lo:hi], top, recipe, n_common))
+    return res

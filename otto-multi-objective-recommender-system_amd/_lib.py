@@ -22,6 +22,21 @@ class OttoError(RuntimeError):
     pass
 
 
+class CandParams(C.Structure):
+    # mirrors otto_cand_params (include/otto_cand.h)
+    _fields_ = [
+        ('n_aids', C.c_uint32),
+        ('k', C.c_int32),
+        ('n_matrices', C.c_int32),
+        ('d_mat_y', C.c_void_p * 8),
+        ('d_mat_n', C.c_void_p * 8),
+        ('n_terms', C.c_int32),
+        ('term_matrix', C.c_int32 * 8),
+        ('term_source', C.c_int32 * 8),
+        ('n_common', C.c_int32),
+    ]
+
+
 class CovisParams(C.Structure):
     # mirrors otto_covis_params (include/otto_covis.h)
     _fields_ = [
@@ -60,6 +75,8 @@ SIGNATURES = {
     'otto_covis_copy_records': (_i32, [_vp, _vp, _vp, _vp, _vp]),
     'otto_covis_timings': (_i32, [_vp, C.POINTER(C.c_float)]),
     'otto_debug_calibrate': (_i32, [_vp, _i64, _i32, _vp]),
+    # include/otto_cand.h
+    'otto_cand_lookup': (_i32, [C.POINTER(CandParams), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     # include/otto_mf.h
     'otto_mf_create': (_i32, [C.POINTER(_vp), _i64, _i64, _i32, _i64, _i32]),
     'otto_mf_destroy': (None, [_vp]),

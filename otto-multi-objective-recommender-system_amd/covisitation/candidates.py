@@ -1,0 +1,51 @@
+"""Covisitation candidate lookup on the device: the per-session loop of the reference's
+``src/ranker/covisitation_candidate_generation.py:108-157`` over the builder's resident top-k arrays."""
+import ctypes as C
+
+from .. import _lib
+
+SOURCES = {'U': 0, 'CC': 1, 'CO': 2}
+# recipes of covisitation_candidate_generation.py:127,133,138
+CLICK_RECIPE = (('time_weighted', 'U'), ('click_weighted', 'CC'), ('cart_weighted', 'CC'), ('click_cart', 'CC'), ('cart_order', 'CC'))
+CART_RECIPE = (('time_weighted', 'U'), ('cart_weighted', 'CC'), ('cart_order', 'CC'))
+ORDER_RECIPE = CART_RECIPE
+
+
+def candidate_lookup(aid, typ, sess_off, matrices, recipe, n_common=100):
+    """``matrices``: {kind: (aid_y int32 [n_aids,k], W, n int32 [n_aids])} as returned by ``CovisBuilder.finalize``.
+    Returns (cand int32 [S, n_common] (-1 padded), count int32 [S, n_common], n int32 [S]) on the device."""
+    import torch
+    dev = aid.device
+    if dev.type != 'cuda':
+        raise _lib.OttoError('candidate_lookup needs a ROCm device (no CPU fallback)')
+    kinds = []
+    for kind, _ in recipe:
+        if kind not in kinds:
+            kinds.append(kind)
+    p = _lib.CandParams()
+    y0 = matrices[kinds[0]][0]
+    p.n_aids, p.k, p.n_matrices = int(y0.shape[0]), int(y0.shape[1]), len(kinds)
+    keep = []
+    for i, kind in enumerate(kinds):
+        y, n = matrices[kind][0], matrices[kind][-1]
+        if y.dtype != torch.int32 or n.dtype != torch.int32 or not y.is_contiguous() or not n.is_contiguous() or y.shape != y0.shape:
+            raise ValueError(f'matrix {kind}: expected contiguous int32 [n_aids, k] / [n_aids]')
+        keep.append((y, n))
+        p.d_mat_y[i], p.d_mat_n[i] = y.data_ptr(), n.data_ptr()
+    p.n_terms = len(recipe)
+    for t, (kind, src) in enumerate(recipe):
+        p.term_matrix[t], p.term_source[t] = kinds.index(kind), SOURCES[src]
+    p.n_common = int(n_common)
+    S = sess_off.numel() - 1
+    cand = torch.empty((S, n_common), dtype=torch.int32, device=dev)
+    count = torch.empty((S, n_common), dtype=torch.int32, device=dev)
+    n_out = torch.empty(S, dtype=torch.int32, device=dev)
+    for name, x, dt in (('aid', aid, torch.int32), ('type', typ, torch.uint8), ('sess_off', sess_off, torch.int64)):
+        if x.dtype != dt or not x.is_contiguous():
+            raise ValueError(f'{name}: expected contiguous {dt}')
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().otto_cand_lookup(C.byref(p), C.c_void_p(aid.data_ptr()), C.c_void_p(typ.data_ptr()),
+                                               C.c_void_p(sess_off.data_ptr()), S, C.c_void_p(cand.data_ptr()),
+                                               C.c_void_p(count.data_ptr()), C.c_void_p(n_out.data_ptr()),
+                                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), 'otto_cand_lookup')
+    return cand, count, n_out

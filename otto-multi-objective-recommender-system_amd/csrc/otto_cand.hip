@@ -1,0 +1,338 @@
+// Covisitation candidate lookup. C-ABI and reference citations: include/otto_cand.h.
+//
+// One 256-thread workgroup per session:
+//   A  load the session; per event: is it the last occurrence of its aid (-> U, most recent first), the first
+//      click/cart (-> CC) or cart/order (-> CO) occurrence; ranks of the sorted lists by counting smaller aids
+//   B  flattened (term, source aid) list: list lengths from the matrices, block exclusive scan = position of every
+//      list in the concatenation the reference builds
+//   C  hash the list entries into an LDS table: one 64-bit word  aid << 32 | count  (ds_add) and a 32-bit first
+//      position (ds_min). Sessions whose concatenation exceeds the table are processed in hash partitions whose
+//      results are merged exactly (partitions hold disjoint aids)
+//   D  Counter.most_common(n_common): composite key count << 50 | ~first_pos << 26 | aid, two 64-wide block
+//      selections (topk.h), then drop the session's own aids and compact
+#include "common.h"
+#include "topk.h"
+#include "../../include/otto_cand.h"
+
+#include <string.h>
+
+namespace otto {
+
+constexpr int CD_THREADS = 256;
+constexpr int CD_NW = CD_THREADS / 64;
+constexpr int CD_MAXL = OTTO_CAND_MAX_SESSION;
+constexpr int CD_LOG2T = 12;
+constexpr int CD_T = 1 << CD_LOG2T;
+constexpr int CD_MPL = CD_T / CD_THREADS;            // table slots per thread
+constexpr int CD_CAP = 3072;                         // list entries per hash partition (load <= 3/4)
+constexpr int CD_MAXQ = OTTO_CAND_MAX_TERMS * CD_MAXL;
+constexpr uint64_t CD_EMPTY = ~0ull;
+constexpr int CD_EXCAP = 64;
+
+struct CandArgs {
+    otto_cand_params p;
+    const uint32_t* aid;
+    const uint8_t* type;
+    const int64_t* sess_off;
+    int64_t n_sess;
+    int32_t* cand;
+    int32_t* count;
+    int32_t* n_out;
+    uint32_t* err;
+};
+
+__device__ __forceinline__ uint64_t cand_key(uint64_t count, uint32_t fp, uint32_t y) {
+    return (count << 50) | ((uint64_t)(0xFFFFFFu - fp) << 26) | (uint64_t)y;
+}
+
+__global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
+    __shared__ uint32_t s_aid[CD_MAXL];
+    __shared__ uint8_t s_ty[CD_MAXL];
+    __shared__ uint8_t s_flag[CD_MAXL];               // bit0 last occurrence, bit1 first click/cart, bit2 first cart/order
+    __shared__ uint32_t s_src[3][CD_MAXL];
+    __shared__ uint32_t s_nsrc[3];
+    __shared__ uint32_t s_base[CD_MAXQ];               // position of list q in the concatenation | len << 24
+    __shared__ unsigned long long s_tab[CD_T];        // aid << 32 | count
+    __shared__ uint32_t s_fp[CD_T];                    // first position
+    __shared__ uint64_t s_sel[OTTO_CAND_MAX_COMMON];   // running most_common list (sorted)
+    __shared__ uint64_t s_lb[CD_THREADS];
+    __shared__ uint64_t s_ex[CD_EXCAP];
+    __shared__ uint64_t s_thr;
+    __shared__ uint32_t s_nex, s_more, s_ovf, s_scan[CD_NW + 1], s_keep[2];
+
+    const int tid = threadIdx.x, wid = tid >> 6;
+    const unsigned lane = lane_id();
+    const int K = a.p.k, NC = a.p.n_common;
+
+    for (int64_t s = blockIdx.x; s < a.n_sess; s += gridDim.x) {
+        const int64_t lo = a.sess_off[s], hi = a.sess_off[s + 1];
+        const int n = (int)(hi - lo);
+        if (n > CD_MAXL) {
+            if (tid == 0) atomicAdd(a.err, 1u);
+            continue;
+        }
+        // ---- A ----------------------------------------------------------------------------------------
+        for (int i = tid; i < n; i += CD_THREADS) { s_aid[i] = a.aid[lo + i]; s_ty[i] = a.type[lo + i]; }
+        if (tid < 3) s_nsrc[tid] = 0;
+        for (int i = tid; i < NC; i += CD_THREADS) s_sel[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += CD_THREADS) {
+            const uint32_t ai = s_aid[i];
+            const uint32_t ti = s_ty[i];
+            bool last = true, fcc = ti <= 1, fco = ti >= 1;
+            for (int j = 0; j < n; ++j) {
+                if (s_aid[j] != ai) continue;
+                if (j > i) last = false;
+                if (j < i && s_ty[j] <= 1) fcc = false;
+                if (j < i && s_ty[j] >= 1) fco = false;
+            }
+            s_flag[i] = (uint8_t)((last ? 1 : 0) | (fcc ? 2 : 0) | (fco ? 4 : 0));
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += CD_THREADS) {
+            const uint32_t ai = s_aid[i], fl = s_flag[i];
+            uint32_t ru = 0, rcc = 0, rco = 0;
+            for (int j = 0; j < n; ++j) {
+                const uint32_t fj = s_flag[j], aj = s_aid[j];
+                ru += (j > i) & (fj & 1u);
+                rcc += ((fj >> 1) & 1u) & (aj < ai);
+                rco += ((fj >> 2) & 1u) & (aj < ai);
+            }
+            if (fl & 1u) { s_src[0][ru] = ai; atomicAdd(&s_nsrc[0], 1u); }
+            if (fl & 2u) { s_src[1][rcc] = ai; atomicAdd(&s_nsrc[1], 1u); }
+            if (fl & 4u) { s_src[2][rco] = ai; atomicAdd(&s_nsrc[2], 1u); }
+        }
+        __syncthreads();
+        // ---- B ----------------------------------------------------------------------------------------
+        uint32_t tstart[OTTO_CAND_MAX_TERMS + 1];
+        tstart[0] = 0;
+#pragma unroll
+        for (int t = 0; t < OTTO_CAND_MAX_TERMS; ++t)
+            tstart[t + 1] = tstart[t] + (t < a.p.n_terms ? s_nsrc[a.p.term_source[t]] : 0u);
+        const uint32_t Q = tstart[OTTO_CAND_MAX_TERMS];
+        uint32_t running = 0;
+        for (uint32_t q0 = 0; q0 < Q; q0 += CD_THREADS) {
+            const uint32_t q = q0 + tid;
+            uint32_t len = 0;
+            if (q < Q) {
+                int t = 0;
+#pragma unroll
+                for (int u = 1; u < OTTO_CAND_MAX_TERMS; ++u) t += (q >= tstart[u]) ? 1 : 0;
+                const uint32_t x = s_src[a.p.term_source[t]][q - tstart[t]];
+                const int32_t ln = x < a.p.n_aids ? a.p.d_mat_n[a.p.term_matrix[t]][x] : 0;
+                len = ln < 0 ? 0u : (uint32_t)(ln > K ? K : ln);
+            }
+            uint32_t tot;
+            const uint32_t off = block_excl_scan<uint32_t, CD_THREADS>(len, s_scan, &tot);
+            if (q < Q) s_base[q] = (running + off) | (len << 24);
+            running += tot;
+        }
+        const uint32_t TOT = running;
+        int lgR = 0;
+        while (((uint32_t)CD_CAP << lgR) < TOT) ++lgR;
+        __syncthreads();
+        // ---- C + D per hash partition (if a partition ever fills the table: start over with twice as many) ----------
+        for (bool again = true; again; ++lgR) {
+        again = false;
+        const uint32_t R = 1u << lgR;
+        if (tid == 0) s_ovf = 0;
+        for (int i = tid; i < NC; i += CD_THREADS) s_sel[i] = 0;
+        __syncthreads();
+        for (uint32_t part = 0; part < R; ++part) {
+            for (int i = tid; i < CD_T; i += CD_THREADS) { s_tab[i] = CD_EMPTY; s_fp[i] = 0xFFFFFFFFu; }
+            __syncthreads();
+            const int hw = tid >> 5, l = tid & 31;
+            for (uint32_t q = hw; q < Q; q += CD_THREADS / 32) {
+                const uint32_t b = s_base[q];
+                const uint32_t len = b >> 24, base = b & 0xFFFFFFu;
+                if ((uint32_t)l < len) {
+                    int t = 0;
+#pragma unroll
+                    for (int u = 1; u < OTTO_CAND_MAX_TERMS; ++u) t += (q >= tstart[u]) ? 1 : 0;
+                    const uint32_t x = s_src[a.p.term_source[t]][q - tstart[t]];
+                    const uint32_t y = (uint32_t)a.p.d_mat_y[a.p.term_matrix[t]][(size_t)x * K + l];
+                    const uint32_t h = y * 0x9E3779B1u;
+                    if (lgR == 0 || ((h >> (32 - CD_LOG2T - lgR)) & (R - 1u)) == part) {
+                        uint32_t slot = h >> (32 - CD_LOG2T);
+                        bool placed = false;
+                        for (int probe = 0; probe < CD_T; ++probe) {
+                            const unsigned long long v = s_tab[slot];
+                            bool mine = v != CD_EMPTY && (uint32_t)(v >> 32) == y;
+                            if (v == CD_EMPTY) {
+                                const unsigned long long old = atomicCAS(&s_tab[slot], (unsigned long long)CD_EMPTY, (unsigned long long)y << 32);
+                                mine = old == CD_EMPTY || (uint32_t)(old >> 32) == y;
+                            }
+                            if (mine) {
+                                atomicAdd(&s_tab[slot], 1ull);
+                                atomicMin(&s_fp[slot], base + (uint32_t)l);
+                                placed = true;
+                                break;
+                            }
+                            slot = (slot + 1) & (CD_T - 1);
+                        }
+                        if (!placed) s_ovf = 1;
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_ovf) { again = true; break; }
+            // candidates of this lane: its table slots and (carried over from earlier partitions) two entries of s_sel
+            auto cand_of = [&](int q) -> KeyN {
+                KeyN k;
+                k.c = 0;
+                if (q < CD_MPL) {
+                    const int i = q * CD_THREADS + tid;
+                    const unsigned long long v = s_tab[i];
+                    if (v != CD_EMPTY) k.c = cand_key(v & 0xFFFFFFFFull, s_fp[i], (uint32_t)(v >> 32));
+                } else {
+                    const int i = tid + (q - CD_MPL) * CD_THREADS;
+                    if (part > 0 && i < NC) k.c = s_sel[i];
+                }
+                return k;
+            };
+            constexpr int NCAND = CD_MPL + 1;                    // NC <= 128 <= CD_THREADS: one carried entry per thread
+            uint64_t selA = 0, selB = 0;                          // lane i of wave 0: i-th / (64+i)-th most common
+            uint64_t limit = ~0ull;                               // round 2 only takes keys below the 64th of round 1
+            for (int round = 0; round < 2; ++round) {
+                const int kk = round == 0 ? (NC < 64 ? NC : 64) : NC - 64;
+                if (kk <= 0) break;
+                KeyN lb;
+                lb.c = 0;
+                uint32_t done = 0;
+                int bi = -1;
+#pragma unroll 2
+                for (int q = 0; q < NCAND; ++q) {
+                    const KeyN c = cand_of(q);
+                    if (c.c < limit && kbetter(c, lb)) { lb = c; bi = q; }
+                }
+                if (bi >= 0) done |= 1u << bi;
+                s_lb[tid] = lb.c;
+                if (tid == 0) { s_nex = 0; s_more = 0; }
+                __syncthreads();
+                KeyN best;
+                best.c = 0;
+                if (wid == 0) {
+                    KeyN lbs[CD_NW];
+#pragma unroll
+                    for (int q = 0; q < CD_NW; ++q) lbs[q].c = s_lb[q * 64 + lane];
+                    wave_topk_select<CD_NW, KeyN>(lbs, kk, best);
+                    const KeyN thr = kshfl(best, kk - 1);
+                    if (lane == 0) s_thr = thr.c;
+                }
+                for (;;) {
+                    __syncthreads();
+                    const uint64_t thr = s_thr;
+#pragma unroll 2
+                    for (int q = 0; q < NCAND; ++q) {
+                        if ((done >> q) & 1u) continue;
+                        const KeyN c = cand_of(q);
+                        if (c.c != 0 && c.c < limit && c.c > thr) {
+                            const uint32_t pos = atomicAdd(&s_nex, 1u);
+                            if (pos < (uint32_t)CD_EXCAP) { s_ex[pos] = c.c; done |= 1u << q; }
+                            else s_more = 1;
+                        }
+                    }
+                    __syncthreads();
+                    const bool more = s_more != 0;
+                    if (wid == 0) {
+                        const uint32_t ne = s_nex < (uint32_t)CD_EXCAP ? s_nex : (uint32_t)CD_EXCAP;
+                        KeyN cnd;
+                        cnd.c = lane < ne ? s_ex[lane] : 0ull;
+                        wave_topk_push(best, cnd, kk);
+                        const KeyN t2 = kshfl(best, kk - 1);
+                        if (more && lane == 0) s_thr = t2.c;
+                    }
+                    if (!more) break;
+                    __syncthreads();
+                    if (tid == 0) { s_nex = 0; s_more = 0; }
+                }
+                if (wid == 0) {
+                    if (round == 0) selA = (int)lane < kk ? best.c : 0ull;
+                    else selB = (int)lane < kk ? best.c : 0ull;
+                    const uint64_t lim = kshfl(best, kk - 1).c;
+                    if (lane == 0) s_thr = lim;
+                }
+                __syncthreads();
+                limit = s_thr;                 // 64th key of round 1 (0 if fewer than 64 candidates -> round 2 finds nothing)
+                if (limit == 0) break;
+                __syncthreads();
+            }
+            __syncthreads();
+            if (wid == 0) {
+                s_sel[lane] = selA;
+                if (64 + (int)lane < NC) s_sel[64 + lane] = selB;
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        }
+        // ---- drop the session's own aids, compact, write ---------------------------------------------------
+        const uint32_t nU = s_nsrc[0];
+        bool keep = false;
+        uint32_t y = 0, cnt = 0;
+        if (tid < NC) {
+            const uint64_t c = s_sel[tid];
+            if (c != 0) {
+                y = (uint32_t)(c & 0x3FFFFFFull);
+                cnt = (uint32_t)(c >> 50);
+                keep = true;
+                for (uint32_t j = 0; j < nU; ++j)
+                    if (s_src[0][j] == y) keep = false;
+            }
+        }
+        const uint64_t bal = __ballot(keep);
+        if (wid < 2 && lane == 0) s_keep[wid] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        if (wid < 2) {
+            const uint32_t pos = (wid == 1 ? s_keep[0] : 0u) + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (keep) {
+                a.cand[s * NC + pos] = (int32_t)y;
+                a.count[s * NC + pos] = (int32_t)cnt;
+            }
+        }
+        const uint32_t total = s_keep[0] + (NC > 64 ? s_keep[1] : 0u);
+        for (int i = (int)total + tid; i < NC; i += CD_THREADS) { a.cand[s * NC + i] = -1; a.count[s * NC + i] = 0; }
+        if (tid == 0) a.n_out[s] = (int32_t)total;
+        __syncthreads();
+    }
+}
+
+}  // namespace otto
+
+using namespace otto;
+
+extern "C" int otto_cand_lookup(const otto_cand_params* p, const uint32_t* d_aid, const uint8_t* d_type, const int64_t* d_sess_off,
+                                int64_t n_sess, int32_t* d_cand, int32_t* d_count, int32_t* d_n, void* stream) {
+    OTTO_REQUIRE(p && d_sess_off && d_cand && d_count && d_n, "otto_cand_lookup: null argument");
+    OTTO_REQUIRE(p->n_aids > 0 && p->n_aids <= (1u << 26), "n_aids must be in [1, 2^26]");
+    OTTO_REQUIRE(p->k >= 1 && p->k <= 32, "k must be in [1, 32]");
+    OTTO_REQUIRE(p->n_matrices >= 1 && p->n_matrices <= OTTO_CAND_MAX_MATRICES, "n_matrices out of range");
+    OTTO_REQUIRE(p->n_terms >= 1 && p->n_terms <= OTTO_CAND_MAX_TERMS, "n_terms out of range");
+    OTTO_REQUIRE(p->n_common >= 1 && p->n_common <= OTTO_CAND_MAX_COMMON, "n_common must be in [1, 128]");
+    for (int m = 0; m < p->n_matrices; ++m) OTTO_REQUIRE(p->d_mat_y[m] && p->d_mat_n[m], "matrix %d is null", m);
+    for (int t = 0; t < p->n_terms; ++t) {
+        OTTO_REQUIRE(p->term_matrix[t] >= 0 && p->term_matrix[t] < p->n_matrices, "term %d: bad matrix", t);
+        OTTO_REQUIRE(p->term_source[t] >= 0 && p->term_source[t] <= 2, "term %d: bad source", t);
+    }
+    if (n_sess <= 0) return 0;
+    OTTO_REQUIRE(d_aid && d_type, "null event arrays");
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t* d_err = nullptr;
+    OTTO_HIP(hipMalloc(&d_err, 4));
+    OTTO_HIP(hipMemsetAsync(d_err, 0, 4, s));
+    CandArgs a;
+    memset(&a, 0, sizeof a);
+    a.p = *p;
+    a.aid = d_aid; a.type = d_type; a.sess_off = d_sess_off; a.n_sess = n_sess;
+    a.cand = d_cand; a.count = d_count; a.n_out = d_n; a.err = d_err;
+    const int grid = (int)(n_sess < 256 * 8 ? n_sess : 256 * 8);
+    k_cand<<<grid, CD_THREADS, 0, s>>>(a);
+    hipError_t le = hipGetLastError();
+    uint32_t err = 0;
+    hipError_t ce = hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s);
+    hipError_t se = hipStreamSynchronize(s);
+    (void)hipFree(d_err);
+    OTTO_REQUIRE(le == hipSuccess && ce == hipSuccess && se == hipSuccess, "k_cand failed: %s", hipGetErrorString(le != hipSuccess ? le : (ce != hipSuccess ? ce : se)));
+    OTTO_REQUIRE(err == 0, "%u session(s) longer than %d events", err, OTTO_CAND_MAX_SESSION);
+    return 0;
+}

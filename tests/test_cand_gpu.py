@@ -1,0 +1,66 @@
+"""GPU parity of the candidate lookup (section 8 f1) against the oracle that restates the reference's loop with Python's
+own Counter.most_common: candidates, their order (count desc, first-insertion ties) and counts must match exactly."""
+import numpy as np
+import pytest
+
+import cand_oracle as cdo
+from otto_amd.synth import generate_sessions, Events
+from otto_amd.covisitation import spec as cs
+
+pytestmark = pytest.mark.gpu
+
+
+def _matrices(ev, dev, k=20):
+    import torch
+    from otto_amd.covisitation.engine import CovisBuilder
+    b = CovisBuilder(ev.n_aids, kinds=cs.REFERENCE_KINDS, ts_min=int(ev.ts.min()), ts_max=int(ev.ts.max()), device=dev)
+    b.feed(torch.from_numpy(ev.aid.astype(np.int32)).to(dev), torch.from_numpy(ev.ts).to(dev), torch.from_numpy(ev.type).to(dev),
+           torch.from_numpy(ev.sess_off).to(dev))
+    return b.finalize(k=k)
+
+
+def _check(ev_train, ev_val, dev, recipes, n_common=100, k=20):
+    import torch
+    from otto_amd.covisitation.candidates import candidate_lookup
+    mats = _matrices(ev_train, dev, k=k)
+    top = {kind: cdo.matrix_to_dict(mats[kind][0].cpu().numpy(), mats[kind][2].cpu().numpy()) for kind in cs.REFERENCE_KINDS}
+    aid = torch.from_numpy(ev_val.aid.astype(np.int32)).to(dev)
+    typ = torch.from_numpy(ev_val.type).to(dev)
+    off = torch.from_numpy(ev_val.sess_off).to(dev)
+    for recipe in recipes:
+        cand, cnt, n = candidate_lookup(aid, typ, off, mats, recipe, n_common=n_common)
+        cand, cnt, n = cand.cpu().numpy(), cnt.cpu().numpy(), n.cpu().numpy()
+        want = cdo.all_candidates(ev_val.aid, ev_val.type, ev_val.sess_off, top, recipe, n_common)
+        for s, (wa, wc) in enumerate(want):
+            assert n[s] == len(wa), f'session {s}: {n[s]} candidates vs {len(wa)}'
+            assert cand[s, :n[s]].tolist() == wa, f'session {s}: candidate order differs'
+            assert cnt[s, :n[s]].tolist() == wc, f'session {s}: counts differ'
+            assert (cand[s, n[s]:] == -1).all()
+
+
+def test_candidates_match_reference_loop(gpu_device):
+    ev = generate_sessions(6000, n_aids=1500, seed=5)
+    val = generate_sessions(800, n_aids=1500, seed=6)
+    _check(ev, val, gpu_device, (cdo.CLICK_RECIPE, cdo.CART_RECIPE))
+
+
+def test_candidates_ties_small_vocabulary_and_other_n_common(gpu_device):
+    """Few aids: every list overlaps, counts tie constantly -> order is decided by first insertion everywhere."""
+    ev = generate_sessions(3000, n_aids=60, seed=7)
+    val = generate_sessions(300, n_aids=60, seed=8)
+    _check(ev, val, gpu_device, (cdo.CLICK_RECIPE,), n_common=20)
+    _check(ev, val, gpu_device, (cdo.CART_RECIPE,), n_common=100)
+
+
+def test_candidates_long_sessions_use_hash_partitions(gpu_device):
+    """500-event sessions with hundreds of distinct aids: the concatenation (tens of thousands of entries) is processed
+    in hash partitions and merged; plus sessions of a single event and of one repeated aid."""
+    rng = np.random.default_rng(3)
+    ev = generate_sessions(20000, n_aids=5000, seed=9)
+    L = np.array([500, 1, 480, 7, 300, 2])
+    off = np.r_[0, np.cumsum(L)].astype(np.int64)
+    aid = rng.integers(0, 5000, off[-1]).astype(np.uint32)
+    aid[off[3]:off[4]] = 77
+    typ = rng.integers(0, 3, off[-1]).astype(np.uint8)
+    val = Events(aid=aid, ts=np.zeros(off[-1], dtype=np.int32), type=typ, sess_off=off, n_aids=5000)
+    _check(ev, val, gpu_device, (cdo.CLICK_RECIPE, cdo.ORDER_RECIPE))
