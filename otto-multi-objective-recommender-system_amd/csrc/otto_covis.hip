@@ -415,6 +415,204 @@ __global__ __launch_bounds__(256) void k_expand_fast(ExpandArgs a) {
     }
 }
 
+// ---- fused, register-only expansion (no filter kinds) -------------------------------------------------
+// Sessions are taken in MEMORY ORDER, 64 per wave round: the wave reads their offsets / slot bases coalesced,
+// sorts them by window class (size n <= 8 / 16 / 32  x  gap-free or not) into a wave-private LDS task list
+// with ballots, then runs the six classes back to back with G = 8 / 16 / 32 lanes per window. Neighbouring
+// sessions are expanded by the same wave, so every event cache line is fetched once (the class-sorted launches
+// above fetch it up to 6x), and there is one launch instead of six.
+//
+// A window lives in registers: lane g = event j; `same` = lanes of my window holding my aid (my class),
+// class id = first such lane, reps = first lanes. Row class r owns slots [rank(r) * (d - 1), +d - 1) of the
+// window (d distinct aids). Masks are kept in WAVE bit space (lane numbers), so a ballot is used as it comes.
+//
+// gap-free windows (span <= max_gap: every pair of distinct aids is valid, first pair = (first x, first y)):
+//   loop over row ranks k: every rep lane stores its own word into row k (skipping its own row).
+// general windows: row loop over i (uniform): pair (i, g) valid if aids differ and |dt| <= max_gap. The class
+//   pair (class(i), my class) is taken by the FIRST valid (i, j) in lexicographic order = first row whose valid
+//   mask meets my class (`done` bit per x class: identical in all lanes of a class because it only depends on
+//   ballot & same), lowest valid lane of the class. The row's fill level = number of column classes that
+//   already took the pair. Run length of class r = popc(done of r): the relation "x and y have a valid pair" is
+//   symmetric (no filter masks here). No M matrix, no LDS atomics: LDS only broadcasts one uint4 per row.
+template <int G, bool TIME, bool FAST>
+__device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, uint32_t* xs, unsigned lane, int n,
+                                                int64_t wstart, uint64_t pbase, uint64_t ebase) {
+    constexpr int WPW = 64 / G;
+    const int g = (int)(lane & (G - 1));
+    const unsigned w0 = lane - g;                               // first lane of my window
+    uint4* evw = ev + w0;
+    int nmax = 0;
+#pragma unroll
+    for (int q = 0; q < WPW; ++q) {
+        const int nq = __builtin_amdgcn_readlane(n, q * G);
+        nmax = nq > nmax ? nq : nmax;
+    }
+    const int nmax4 = (nmax + 3) & ~3;
+    const bool act = g < n;
+    uint32_t aid = 0xFFFFFFFFu, ty = 0, extra = 0;
+    int32_t t = 0;
+    if (act) {
+        aid = a.aid[wstart + g];
+        ty = a.type[wstart + g];
+        if (!FAST || TIME) t = a.ts[wstart + g];
+        if (TIME) extra = a.tspan > 0 ? (uint32_t)((uint64_t)(196608ull * (uint64_t)((int64_t)t - a.t0)) / (uint64_t)a.tspan) : 0u;
+    }
+    ev[lane] = make_uint4(aid, (uint32_t)t, 0u, extra);
+    wave_lds_sync();
+    uint32_t same = 0;                                          // window-relative bits
+    for (int j0 = 0; j0 < nmax4; j0 += 4) {
+        uint32_t ax[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ax[u] = evw[(j0 + u) & (G - 1)].x;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) same |= (ax[u] == aid ? 1u : 0u) << ((j0 + u) & 31);
+    }
+    same &= n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    const int cls = act ? (int)__builtin_ctz(same) : g;
+    const bool rep = act && cls == g;
+    // wave-space 64-bit masks of my window / the lanes of my window below me
+    const uint64_t win64 = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << w0;
+    const uint64_t lw64 = win64 & ((1ull << lane) - 1ull);
+    const uint64_t rep64 = __ballot(rep);
+    const uint32_t d1 = (uint32_t)__popcll(rep64 & win64) - 1u;                  // records a full row holds
+    uint32_t* recp = a.rec + (a.rec_base + pbase);
+    uint32_t* twp = TIME ? a.tw + (a.rec_base + pbase) : nullptr;
+    const uint32_t word = aid | (ty << REC_AID_BITS);
+    if (FAST) {
+        const uint32_t below = (uint32_t)__popcll(rep64 & lw64);                 // my rank among the reps
+        if (TIME) {
+            if (rep) xs[w0 + below] = extra;
+            wave_lds_sync();
+        }
+        int dmax = 0;
+#pragma unroll
+        for (int q = 0; q < WPW; ++q) {
+            const int dq = __builtin_amdgcn_readlane((int)d1, q * G) + 1;
+            dmax = dq > dmax ? dq : dmax;
+        }
+        for (int k = 0; k < dmax; ++k) {
+            if (rep && (uint32_t)k <= d1 && (uint32_t)k != below) {
+                const uint32_t o = (uint32_t)k * d1 + below - (below > (uint32_t)k ? 1u : 0u);
+                recp[o] = word;
+                if (TIME) twp[o] = xs[w0 + k];
+            }
+        }
+        if (act) {
+            a.run_x[a.run_base + ebase + g] = aid;
+            a.run_desc[a.run_base + ebase + g] = (rep && d1) ? (((a.rec_base + pbase + (uint64_t)below * d1) << 8) | d1) : 0ull;
+        }
+        wave_lds_sync();
+        return;
+    }
+    const uint32_t rb = (uint32_t)__popcll(rep64 & win64 & ((1ull << (w0 + cls)) - 1ull)) * d1;   // first slot of my class's row
+    reinterpret_cast<uint32_t*>(&ev[lane])[2] = (uint32_t)cls | (rb << 5);
+    wave_lds_sync();
+    const uint64_t same64 = (uint64_t)same << w0;
+    const uint64_t samelow64 = same64 & lw64;
+    uint32_t done = 0;
+    uint4 e = evw[0];
+    for (int i = 0; i < nmax; ++i) {
+        const uint4 en = evw[(i + 1) & (G - 1)];                // next row in flight
+        const uint32_t dA = e.y - (uint32_t)t, dB = (uint32_t)t - e.y;
+        const uint32_t ad = dA < dB ? dA : dB;                    // |dt| (|dt| < 2^31)
+        const bool valid = act && i < n && e.x != aid && ad <= (uint32_t)a.max_gap;
+        const uint64_t V = __ballot(valid);
+        const bool mine = (V & same64) != 0;
+        const uint32_t ci = e.z & 31u;
+        const bool seen = (done >> ci) & 1u;
+        const bool emit = valid && !seen && (V & samelow64) == 0;
+        const uint64_t D = __ballot(rep && seen);
+        const uint64_t E = __ballot(emit);
+        if (mine) done |= 1u << ci;
+        if (emit) {
+            const uint32_t o = (e.z >> 5) + (uint32_t)__popcll(D & win64) + (uint32_t)__popcll(E & lw64);
+            recp[o] = word;
+            if (TIME) twp[o] = e.w;
+        }
+        e = en;
+    }
+    if (act) {
+        const uint32_t len = rep ? __popc(done) : 0u;
+        a.run_x[a.run_base + ebase + g] = aid;
+        a.run_desc[a.run_base + ebase + g] = len ? (((a.rec_base + pbase + rb) << 8) | len) : 0ull;
+    }
+    wave_lds_sync();
+}
+
+template <bool TIME>
+__global__ __launch_bounds__(256) void k_expand_fused(ExpandArgs a, int64_t n_sess, int use_fast) {
+    __shared__ uint4 s_ev[4][64];
+    __shared__ uint32_t s_xs[4][TIME ? 64 : 1];
+    __shared__ uint4 s_ta[4][64];       // task: wstart lo, wstart hi | n << 16, pair_base lo, hi
+    __shared__ uint2 s_tb[4][64];       //       ev_base lo, hi
+    const int wv = threadIdx.x >> 6;
+    const unsigned lane = lane_id();
+    uint4* ev = s_ev[wv];
+    uint32_t* xs = s_xs[wv];
+    uint4* ta = s_ta[wv];
+    uint2* tb = s_tb[wv];
+    const int64_t n_tiles = (n_sess + 63) / 64;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t s = tile * 64 + lane;
+        int n = 0, c6 = 6;
+        int64_t wstart = 0;
+        uint64_t pb = 0, eb = 0;
+        if (s < n_sess) {
+            const int64_t lo = a.sess_off[s], hi = a.sess_off[s + 1];
+            const int64_t len = hi - lo;
+            n = (int)(len < a.window ? len : a.window);
+            wstart = hi - n;
+            pb = a.pair_base[s];
+            eb = a.ev_base[s];
+            if (n >= 2) {
+                c6 = n <= 8 ? 0 : (n <= 16 ? 1 : 2);
+                if (use_fast && (int64_t)a.ts[hi - 1] - (int64_t)a.ts[wstart] <= (int64_t)a.max_gap) c6 += 3;
+            }
+        }
+        int cnt[6], base[6];
+        int below = 0, acc = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const uint64_t m = __ballot(c6 == q);
+            cnt[q] = __popcll(m);
+            base[q] = acc;
+            if (c6 == q) below = acc + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            acc += cnt[q];
+        }
+        if (c6 < 6) {
+            ta[below] = make_uint4((uint32_t)wstart, (uint32_t)((uint64_t)wstart >> 32) | ((uint32_t)n << 16), (uint32_t)pb, (uint32_t)(pb >> 32));
+            tb[below] = make_uint2((uint32_t)eb, (uint32_t)(eb >> 32));
+        }
+        wave_lds_sync();
+        auto run_class = [&](auto gtag, auto ftag, int b0, int c) {
+            constexpr int G = decltype(gtag)::value;
+            constexpr bool FAST = decltype(ftag)::value;
+            constexpr int WPW = 64 / G;
+            for (int t0 = 0; t0 < c; t0 += WPW) {
+                const int ti = t0 + (int)(lane / G);
+                int tn = 0;
+                int64_t tws = 0;
+                uint64_t tpb = 0, teb = 0;
+                if (ti < c) {
+                    const uint4 A = ta[b0 + ti];
+                    const uint2 B = tb[b0 + ti];
+                    tn = (int)(A.y >> 16);
+                    tws = (int64_t)(((uint64_t)(A.y & 0xFFFFu) << 32) | A.x);
+                    tpb = ((uint64_t)A.w << 32) | A.z;
+                    teb = ((uint64_t)B.y << 32) | B.x;
+                }
+                expand_task_reg<G, TIME, FAST>(a, ev, xs, lane, tn, tws, tpb, teb);
+            }
+        };
+        run_class(std::integral_constant<int, 8>{}, std::false_type{}, base[0], cnt[0]);
+        run_class(std::integral_constant<int, 16>{}, std::false_type{}, base[1], cnt[1]);
+        run_class(std::integral_constant<int, 32>{}, std::false_type{}, base[2], cnt[2]);
+        run_class(std::integral_constant<int, 8>{}, std::true_type{}, base[3], cnt[3]);
+        run_class(std::integral_constant<int, 16>{}, std::true_type{}, base[4], cnt[4]);
+        run_class(std::integral_constant<int, 32>{}, std::true_type{}, base[5], cnt[5]);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // index: histogram / scatter of runs by aid_x, work items
 // ---------------------------------------------------------------------------
@@ -1394,6 +1592,7 @@ struct otto_covis_ctx {
     // chunk scratch
     DevBuf pair_base, ev_base, partial, cls_pos[N_WIN_CLASSES], sess_list, cls_byte;
     int fast_path = 1;
+    int fused = 1;                 // k_expand_fused when no filter kind is configured
     // index
     bool index_valid = false;
     DevBuf cnt64, run_start, run_rank, sorted_desc, item_start, boost, flag, counters;
@@ -1491,8 +1690,45 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
     OTTO_TRY(c->partial.ensure(scan_partial_bytes(n_sess > (int64_t)p.n_aids ? n_sess : (int64_t)p.n_aids), 0, s));
     OTTO_TRY(device_scan(WinPairs{d_sess_off, p.window}, n_sess, c->pair_base.as<uint64_t>(), c->partial.as<uint64_t>(), s));
     OTTO_TRY(device_scan(WinEvents{d_sess_off, p.window}, n_sess, c->ev_base.as<uint64_t>(), c->partial.as<uint64_t>(), s));
-    // window classes (3 sizes x gap-free or not): one session list, six segments
     OTTO_REQUIRE(n_sess < (1ll << 32), "more than 2^32 sessions in one chunk");
+    const bool fused = p.n_filters == 0 && c->fused;
+    if (fused) {
+        // no filter kinds: one fused launch over the sessions in memory order (k_expand_fused), no class lists
+        tend(c, OTTO_COVIS_T_WINSCAN, s);
+        uint64_t tot[2];
+        OTTO_HIP(hipMemcpyAsync(&tot[0], c->pair_base.as<uint64_t>() + n_sess, 8, hipMemcpyDeviceToHost, s));
+        OTTO_HIP(hipMemcpyAsync(&tot[1], c->ev_base.as<uint64_t>() + n_sess, 8, hipMemcpyDeviceToHost, s));
+        OTTO_HIP(hipStreamSynchronize(s));
+        const uint64_t n_slots = tot[0], n_ev = tot[1];
+        OTTO_REQUIRE(c->rec_used + n_slots < (1ull << 55), "record slot space exhausted");
+        OTTO_TRY(c->rec.ensure((size_t)(c->rec_used + n_slots) * 4, (size_t)c->rec_used * 4, s));
+        if (p.want_time) OTTO_TRY(c->tw.ensure((size_t)(c->rec_used + n_slots) * 4, (size_t)c->rec_used * 4, s));
+        OTTO_TRY(c->run_x.ensure((size_t)(c->run_used + n_ev) * 4, (size_t)c->run_used * 4, s));
+        OTTO_TRY(c->run_desc.ensure((size_t)(c->run_used + n_ev) * 8, (size_t)c->run_used * 8, s));
+        tbegin(c, OTTO_COVIS_T_EXPAND, s);
+        ExpandArgs a;
+        memset(&a, 0, sizeof(a));
+        a.aid = d_aid; a.ts = d_ts; a.type = d_type; a.sess_off = d_sess_off;
+        a.pair_base = c->pair_base.as<uint64_t>(); a.ev_base = c->ev_base.as<uint64_t>();
+        a.rec = c->rec.as<uint32_t>(); a.tw = c->tw.as<uint32_t>();
+        a.run_x = c->run_x.as<uint32_t>(); a.run_desc = c->run_desc.as<uint64_t>();
+        a.rec_base = c->rec_used; a.run_base = c->run_used;
+        a.window = p.window; a.max_gap = p.max_gap;
+        a.t0 = p.ts_min; a.tspan = (int64_t)p.ts_max - (int64_t)p.ts_min;
+        const int64_t tiles = (n_sess + 63) / 64;
+        const int64_t blocks = (tiles + 3) / 4;
+        const int grid = (int)(blocks < 256 * 6 ? blocks : 256 * 6);
+        if (p.want_time) k_expand_fused<true><<<grid, 256, 0, s>>>(a, n_sess, c->fast_path);
+        else k_expand_fused<false><<<grid, 256, 0, s>>>(a, n_sess, c->fast_path);
+        OTTO_HIP(hipGetLastError());
+        tend(c, OTTO_COVIS_T_EXPAND, s);
+        c->rec_used += n_slots;
+        c->run_used += n_ev;
+        c->sessions += n_sess;
+        c->index_valid = false;
+        return 0;
+    }
+    // filter kinds: window classes (3 sizes x gap-free or not): one session list, six segments
     const int use_fast = p.n_filters == 0 && c->fast_path;
     OTTO_TRY(c->cls_byte.ensure((size_t)n_sess, 0, s));
     k_classify<<<(unsigned)((n_sess + 255) / 256), 256, 0, s>>>(d_sess_off, d_ts, p.window, p.max_gap, use_fast, n_sess,
@@ -1815,6 +2051,7 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
         return 0;
     }
     if (strcmp(name, "debug_skip") == 0) { c->debug_skip = (int)value; return 0; }   // timing diagnostics, results invalid
+    if (strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }           // fused in-order expansion on/off (A/B)
     if (strcmp(name, "fast_path") == 0) { c->fast_path = value != 0; return 0; }   // gap-free window kernel on/off (A/B)
     if (strcmp(name, "partition") == 0) {
         // 1 (default): bucket heavy aids' records by hash partition once; 0: every partition re-reads
