@@ -191,6 +191,7 @@ struct ExpandArgs {
     int64_t t0;
     int64_t tspan;
     uint32_t fmask[4];
+    int debug;                   // timing diagnostics (wrong results): 1 no record stores, 2 no row loops
 };
 
 // LDS traffic between the lanes of ONE wave: the LDS queue of a wave is in order, so only the compiler
@@ -396,14 +397,14 @@ __global__ __launch_bounds__(256) void k_expand_fast(ExpandArgs a) {
         // row r (a representative) lists every other representative in position order: d - 1 records
         for (int r = 0; r < nmax; ++r) {
             const bool row = (repm >> r) & 1u;                // uniform inside the window
+            // time extra of the row's event: read with ALL lanes active (the source lane g == r sits out the branch)
+            const uint32_t xr = TIME ? (uint32_t)__shfl((int)extra, (int)(grp_shift + r), 64) : 0u;
             if (row && rep && g != r) {
                 const uint32_t rowrank = __popc(repm & ((1u << r) - 1u));
                 const uint32_t rank = below - (g > r ? 1u : 0u);
                 const uint64_t slot = a.rec_base + pbase + (uint64_t)rowrank * (d - 1) + rank;
                 a.rec[slot] = rec_word;
-                if (TIME) a.tw[slot] = (uint32_t)__shfl((int)extra, (int)(grp_shift + r), 64);
-            } else if (TIME) {
-                (void)__shfl((int)extra, (int)(grp_shift + r), 64);
+                if (TIME) a.tw[slot] = xr;
             }
         }
         if (g < n) {
@@ -434,10 +435,44 @@ __global__ __launch_bounds__(256) void k_expand_fast(ExpandArgs a) {
 //   ballot & same), lowest valid lane of the class. The row's fill level = number of column classes that
 //   already took the pair. Run length of class r = popc(done of r): the relation "x and y have a valid pair" is
 //   symmetric (no filter masks here). No M matrix, no LDS atomics: LDS only broadcasts one uint4 per row.
+struct TaskPre {            // one task of a lane's window, its event already requested from memory
+    int n;
+    uint64_t pb, eb;
+    uint32_t aid, ty;
+    int32_t t;
+};
+
+// task `t0 + lane / G` of the list segment [b0, b0 + c): window descriptor from LDS, then the lane's event loads
+// are ISSUED here -- the caller runs the previous task's row loop before touching the values.
+template <int G, bool NEED_TS>
+__device__ __forceinline__ TaskPre fetch_task(const ExpandArgs& a, const uint4* ta, const uint2* tb, int b0, int c, int t0,
+                                              unsigned lane) {
+    TaskPre p;
+    p.n = 0; p.pb = p.eb = 0; p.aid = 0xFFFFFFFFu; p.ty = 0; p.t = 0;
+    const int ti = t0 + (int)(lane / G);
+    int64_t ws = 0;
+    if (ti < c) {
+        const uint4 A = ta[b0 + ti];
+        const uint2 B = tb[b0 + ti];
+        p.n = (int)(A.y >> 16);
+        ws = (int64_t)(((uint64_t)(A.y & 0xFFFFu) << 32) | A.x);
+        p.pb = ((uint64_t)A.w << 32) | A.z;
+        p.eb = ((uint64_t)B.y << 32) | B.x;
+    }
+    const int g = (int)(lane & (G - 1));
+    if (g < p.n) {
+        p.aid = a.aid[ws + g];
+        p.ty = a.type[ws + g];
+        if (NEED_TS) p.t = a.ts[ws + g];
+    }
+    return p;
+}
+
 template <int G, bool TIME, bool FAST>
-__device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, uint32_t* xs, unsigned lane, int n,
-                                                int64_t wstart, uint64_t pbase, uint64_t ebase) {
+__device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, uint32_t* xs, unsigned lane, const TaskPre& tp) {
     constexpr int WPW = 64 / G;
+    const int n = tp.n;
+    const uint64_t pbase = tp.pb, ebase = tp.eb;
     const int g = (int)(lane & (G - 1));
     const unsigned w0 = lane - g;                               // first lane of my window
     uint4* evw = ev + w0;
@@ -449,14 +484,10 @@ __device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, 
     }
     const int nmax4 = (nmax + 3) & ~3;
     const bool act = g < n;
-    uint32_t aid = 0xFFFFFFFFu, ty = 0, extra = 0;
-    int32_t t = 0;
-    if (act) {
-        aid = a.aid[wstart + g];
-        ty = a.type[wstart + g];
-        if (!FAST || TIME) t = a.ts[wstart + g];
-        if (TIME) extra = a.tspan > 0 ? (uint32_t)((uint64_t)(196608ull * (uint64_t)((int64_t)t - a.t0)) / (uint64_t)a.tspan) : 0u;
-    }
+    const uint32_t aid = tp.aid, ty = tp.ty;
+    const int32_t t = tp.t;
+    uint32_t extra = 0;
+    if (TIME && act) extra = a.tspan > 0 ? (uint32_t)((uint64_t)(196608ull * (uint64_t)((int64_t)t - a.t0)) / (uint64_t)a.tspan) : 0u;
     ev[lane] = make_uint4(aid, (uint32_t)t, 0u, extra);
     wave_lds_sync();
     uint32_t same = 0;                                          // window-relative bits
@@ -490,8 +521,9 @@ __device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, 
             const int dq = __builtin_amdgcn_readlane((int)d1, q * G) + 1;
             dmax = dq > dmax ? dq : dmax;
         }
+        if (a.debug & 2) dmax = 0;
         for (int k = 0; k < dmax; ++k) {
-            if (rep && (uint32_t)k <= d1 && (uint32_t)k != below) {
+            if (!(a.debug & 1) && rep && (uint32_t)k <= d1 && (uint32_t)k != below) {
                 const uint32_t o = (uint32_t)k * d1 + below - (below > (uint32_t)k ? 1u : 0u);
                 recp[o] = word;
                 if (TIME) twp[o] = xs[w0 + k];
@@ -511,6 +543,7 @@ __device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, 
     const uint64_t samelow64 = same64 & lw64;
     uint32_t done = 0;
     uint4 e = evw[0];
+    if (a.debug & 2) nmax = 0;
     for (int i = 0; i < nmax; ++i) {
         const uint4 en = evw[(i + 1) & (G - 1)];                // next row in flight
         const uint32_t dA = e.y - (uint32_t)t, dB = (uint32_t)t - e.y;
@@ -524,7 +557,7 @@ __device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, 
         const uint64_t D = __ballot(rep && seen);
         const uint64_t E = __ballot(emit);
         if (mine) done |= 1u << ci;
-        if (emit) {
+        if (emit && !(a.debug & 1)) {
             const uint32_t o = (e.z >> 5) + (uint32_t)__popcll(D & win64) + (uint32_t)__popcll(E & lw64);
             recp[o] = word;
             if (TIME) twp[o] = e.w;
@@ -552,22 +585,30 @@ __global__ __launch_bounds__(256) void k_expand_fused(ExpandArgs a, int64_t n_se
     uint4* ta = s_ta[wv];
     uint2* tb = s_tb[wv];
     const int64_t n_tiles = (n_sess + 63) / 64;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t tile_stride = (int64_t)gridDim.x * 4;
+    // session metadata of a tile (one session per lane), requested one tile ahead
+    struct TilePre { int64_t lo, hi; uint64_t pb, eb; };
+    auto fetch_tile = [&](int64_t tile) {
+        TilePre q;
+        q.lo = q.hi = 0; q.pb = q.eb = 0;
         const int64_t s = tile * 64 + lane;
-        int n = 0, c6 = 6;
-        int64_t wstart = 0;
-        uint64_t pb = 0, eb = 0;
-        if (s < n_sess) {
-            const int64_t lo = a.sess_off[s], hi = a.sess_off[s + 1];
-            const int64_t len = hi - lo;
-            n = (int)(len < a.window ? len : a.window);
-            wstart = hi - n;
-            pb = a.pair_base[s];
-            eb = a.ev_base[s];
-            if (n >= 2) {
-                c6 = n <= 8 ? 0 : (n <= 16 ? 1 : 2);
-                if (use_fast && (int64_t)a.ts[hi - 1] - (int64_t)a.ts[wstart] <= (int64_t)a.max_gap) c6 += 3;
-            }
+        if (tile < n_tiles && s < n_sess) {
+            q.lo = a.sess_off[s]; q.hi = a.sess_off[s + 1];
+            q.pb = a.pair_base[s]; q.eb = a.ev_base[s];
+        }
+        return q;
+    };
+    int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+    TilePre cur = fetch_tile(tile);
+    for (; tile < n_tiles; tile += tile_stride) {
+        const TilePre nxt = fetch_tile(tile + tile_stride);
+        const int64_t len = cur.hi - cur.lo;
+        const int n = (int)(len < a.window ? len : a.window);
+        const int64_t wstart = cur.hi - n;
+        int c6 = 6;
+        if (n >= 2) {
+            c6 = n <= 8 ? 0 : (n <= 16 ? 1 : 2);
+            if (use_fast && (int64_t)a.ts[cur.hi - 1] - (int64_t)a.ts[wstart] <= (int64_t)a.max_gap) c6 += 3;
         }
         int cnt[6], base[6];
         int below = 0, acc = 0;
@@ -580,36 +621,42 @@ __global__ __launch_bounds__(256) void k_expand_fused(ExpandArgs a, int64_t n_se
             acc += cnt[q];
         }
         if (c6 < 6) {
-            ta[below] = make_uint4((uint32_t)wstart, (uint32_t)((uint64_t)wstart >> 32) | ((uint32_t)n << 16), (uint32_t)pb, (uint32_t)(pb >> 32));
-            tb[below] = make_uint2((uint32_t)eb, (uint32_t)(eb >> 32));
+            ta[below] = make_uint4((uint32_t)wstart, (uint32_t)((uint64_t)wstart >> 32) | ((uint32_t)n << 16), (uint32_t)cur.pb, (uint32_t)(cur.pb >> 32));
+            tb[below] = make_uint2((uint32_t)cur.eb, (uint32_t)(cur.eb >> 32));
         }
         wave_lds_sync();
-        auto run_class = [&](auto gtag, auto ftag, int b0, int c) {
+        // classes run back to back; the events of the NEXT task (same class, or the first task of the next class)
+        // are requested before the current task's row loop
+        auto run_class = [&](auto gtag, auto ftag, auto gntag, auto fntag, int q, const TaskPre& first) {
             constexpr int G = decltype(gtag)::value;
             constexpr bool FAST = decltype(ftag)::value;
+            constexpr int GN = decltype(gntag)::value;
+            constexpr bool FASTN = decltype(fntag)::value;
             constexpr int WPW = 64 / G;
+            const int b0 = base[q], c = cnt[q];
+            const int bn = q < 5 ? base[q < 5 ? q + 1 : 5] : 0, cn = q < 5 ? cnt[q < 5 ? q + 1 : 5] : 0;
+            TaskPre tp = first;
             for (int t0 = 0; t0 < c; t0 += WPW) {
-                const int ti = t0 + (int)(lane / G);
-                int tn = 0;
-                int64_t tws = 0;
-                uint64_t tpb = 0, teb = 0;
-                if (ti < c) {
-                    const uint4 A = ta[b0 + ti];
-                    const uint2 B = tb[b0 + ti];
-                    tn = (int)(A.y >> 16);
-                    tws = (int64_t)(((uint64_t)(A.y & 0xFFFFu) << 32) | A.x);
-                    tpb = ((uint64_t)A.w << 32) | A.z;
-                    teb = ((uint64_t)B.y << 32) | B.x;
-                }
-                expand_task_reg<G, TIME, FAST>(a, ev, xs, lane, tn, tws, tpb, teb);
+                TaskPre nx;
+                if (t0 + WPW < c) nx = fetch_task<G, !FAST || TIME>(a, ta, tb, b0, c, t0 + WPW, lane);
+                else nx = fetch_task<GN, !FASTN || TIME>(a, ta, tb, bn, cn, 0, lane);
+                expand_task_reg<G, TIME, FAST>(a, ev, xs, lane, tp);
+                tp = nx;
             }
+            if (c == 0) tp = fetch_task<GN, !FASTN || TIME>(a, ta, tb, bn, cn, 0, lane);
+            return tp;
         };
-        run_class(std::integral_constant<int, 8>{}, std::false_type{}, base[0], cnt[0]);
-        run_class(std::integral_constant<int, 16>{}, std::false_type{}, base[1], cnt[1]);
-        run_class(std::integral_constant<int, 32>{}, std::false_type{}, base[2], cnt[2]);
-        run_class(std::integral_constant<int, 8>{}, std::true_type{}, base[3], cnt[3]);
-        run_class(std::integral_constant<int, 16>{}, std::true_type{}, base[4], cnt[4]);
-        run_class(std::integral_constant<int, 32>{}, std::true_type{}, base[5], cnt[5]);
+        using I8 = std::integral_constant<int, 8>;
+        using I16 = std::integral_constant<int, 16>;
+        using I32 = std::integral_constant<int, 32>;
+        TaskPre tp = fetch_task<8, true>(a, ta, tb, base[0], cnt[0], 0, lane);
+        tp = run_class(I8{}, std::false_type{}, I16{}, std::false_type{}, 0, tp);
+        tp = run_class(I16{}, std::false_type{}, I32{}, std::false_type{}, 1, tp);
+        tp = run_class(I32{}, std::false_type{}, I8{}, std::true_type{}, 2, tp);
+        tp = run_class(I8{}, std::true_type{}, I16{}, std::true_type{}, 3, tp);
+        tp = run_class(I16{}, std::true_type{}, I32{}, std::true_type{}, 4, tp);
+        tp = run_class(I32{}, std::true_type{}, I32{}, std::true_type{}, 5, tp);
+        cur = nxt;
     }
 }
 
@@ -1183,6 +1230,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 atomicAdd(&s_v[0][found], 1u);
                 const uint32_t old = atomicAdd(&s_v[1][found], e);
                 if (old + e < old) atomicAdd(&s_v[2][found], 1u);
+            } else if (GROUP == OTTO_COVIS_GROUP_TYPE) {
+                const uint32_t tyj = (rc >> REC_AID_BITS) & 3u;            // exactly one counter: one LDS atomic, no divergence
+                if (tyj < 3u) atomicAdd(&s_v[tyj][found], 1u);
             } else {
                 if (add0) atomicAdd(&s_v[0][found], 1u);
                 if (add1) atomicAdd(&s_v[1][found], 1u);
@@ -1715,9 +1765,16 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
         a.rec_base = c->rec_used; a.run_base = c->run_used;
         a.window = p.window; a.max_gap = p.max_gap;
         a.t0 = p.ts_min; a.tspan = (int64_t)p.ts_max - (int64_t)p.ts_min;
+        a.debug = c->debug_skip >> 4;
         const int64_t tiles = (n_sess + 63) / 64;
         const int64_t blocks = (tiles + 3) / 4;
-        const int grid = (int)(blocks < 256 * 6 ? blocks : 256 * 6);
+        int per_cu = 0, n_cu = 0, dev = 0;
+        OTTO_HIP(hipGetDevice(&dev));
+        OTTO_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (p.want_time) OTTO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_expand_fused<true>, 256, 0));
+        else OTTO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_expand_fused<false>, 256, 0));
+        const int64_t resident = (int64_t)(per_cu > 0 ? per_cu : 4) * (n_cu > 0 ? n_cu : 256);   // one round of resident workgroups
+        const int grid = (int)(blocks < resident ? blocks : resident);
         if (p.want_time) k_expand_fused<true><<<grid, 256, 0, s>>>(a, n_sess, c->fast_path);
         else k_expand_fused<false><<<grid, 256, 0, s>>>(a, n_sess, c->fast_path);
         OTTO_HIP(hipGetLastError());

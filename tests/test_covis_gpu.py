@@ -11,6 +11,9 @@ from otto_amd.covisitation import spec as cs
 
 pytestmark = pytest.mark.gpu
 
+# kind sets: with filter kinds K1 runs the class-sorted M-matrix kernels, without them the fused register kernel
+NOFILT = ('time_weighted', 'click_weighted', 'cart_weighted', 'order_weighted')
+
 
 def _to_dev(ev, dev):
     import torch
@@ -18,12 +21,14 @@ def _to_dev(ev, dev):
             torch.from_numpy(ev.type).to(dev), torch.from_numpy(ev.sess_off).to(dev))
 
 
-def _build(ev, dev, kinds=cs.ALL_KINDS, k=20, window=30, max_gap=86400, chunks=1, l_cap=None):
+def _build(ev, dev, kinds=cs.ALL_KINDS, k=20, window=30, max_gap=86400, chunks=1, l_cap=None, options=None):
     from otto_amd.covisitation.engine import CovisBuilder, topk_to_rows
     ts_min, ts_max = (int(ev.ts.min()), int(ev.ts.max())) if ev.n_events else (0, 0)
     b = CovisBuilder(ev.n_aids, kinds=kinds, window=window, max_gap=max_gap, ts_min=ts_min, ts_max=ts_max, device=dev)
     if l_cap is not None:
         b.set_option('l_cap', l_cap)
+    for name, value in (options or {}).items():
+        b.set_option(name, value)
     aid, ts, typ, off = _to_dev(ev, dev)
     S = ev.n_sessions
     bounds = np.linspace(0, S, chunks + 1).astype(np.int64)
@@ -99,15 +104,28 @@ def test_pair_expand_records_match_oracle(gpu_device, kinds):
     assert b.stats()['pairs'] == total
 
 
+@pytest.mark.parametrize('kinds', [cs.ALL_KINDS, NOFILT], ids=['all-kinds', 'fused'])
 @pytest.mark.parametrize('n_sessions,n_aids,seed', [(3000, 2000, 11), (20000, 60, 12), (800, 1855603, 13)])
-def test_topk_all_kinds_match_oracle(gpu_device, n_sessions, n_aids, seed):
-    """Full pipeline, all 8 kinds, k=20: small/medium/heavy aids (n_aids=60 makes every aid heavy)."""
+def test_topk_all_kinds_match_oracle(gpu_device, n_sessions, n_aids, seed, kinds):
+    """Full pipeline, k=20: small/medium/heavy aids (n_aids=60 makes every aid heavy); all 8 kinds (class-sorted
+    K1) and the four kinds without a filter mask (fused K1)."""
     ev = generate_sessions(n_sessions, n_aids=n_aids, seed=seed)
     st = {}
-    want = _oracle_rows(ev, cs.ALL_KINDS, stats=st)
-    b, got = _build(ev, gpu_device)
-    _assert_rows_equal(got, want, cs.ALL_KINDS)
+    want = _oracle_rows(ev, kinds, stats=st)
+    b, got = _build(ev, gpu_device, kinds=kinds)
+    _assert_rows_equal(got, want, kinds)
     assert b.stats()['pairs'] == st['P']
+
+
+@pytest.mark.parametrize('options', [{'fast_path': 0}, {'fused': 0}, {'fused': 0, 'fast_path': 0}],
+                         ids=['fused-general-only', 'class-kernels', 'class-kernels-general-only'])
+def test_expand_variants_agree(gpu_device, options):
+    """The fused K1 with its gap-free shortcut switched off (every window through the general row loop), and the
+    class-sorted kernels forced for the same kinds, give the oracle's rows too."""
+    ev = generate_sessions(4000, n_aids=700, seed=17)
+    want = _oracle_rows(ev, NOFILT)
+    _, got = _build(ev, gpu_device, kinds=NOFILT, options=options, chunks=2)
+    _assert_rows_equal(got, want, NOFILT)
 
 
 def test_heavy_aid_partitions_and_overflow_retry(gpu_device):
@@ -140,11 +158,11 @@ def test_chunked_feed_equals_single_feed(gpu_device):
 
 def test_window_gap_and_k_parameters(gpu_device):
     ev = generate_sessions(1200, n_aids=300, seed=31)
-    kinds = ('click_click', 'time_weighted', 'cart_weighted')
-    for window, gap, k in ((5, 600, 3), (32, 10_000_000, 32), (2, 86400, 1)):
-        want = _oracle_rows(ev, kinds, k=k, window=window, max_gap=gap)
-        _, got = _build(ev, gpu_device, kinds=kinds, k=k, window=window, max_gap=gap)
-        _assert_rows_equal(got, want, kinds)
+    for kinds in (('click_click', 'time_weighted', 'cart_weighted'), NOFILT):
+        for window, gap, k in ((5, 600, 3), (32, 10_000_000, 32), (2, 86400, 1), (17, 0, 20), (9, 86400, 20)):
+            want = _oracle_rows(ev, kinds, k=k, window=window, max_gap=gap)
+            _, got = _build(ev, gpu_device, kinds=kinds, k=k, window=window, max_gap=gap)
+            _assert_rows_equal(got, want, kinds)
 
 
 def test_edge_cases(gpu_device):
@@ -155,13 +173,14 @@ def test_edge_cases(gpu_device):
     typ = np.array([0, 1, 2, 0, 0, 1, 2, 0], dtype=np.uint8)
     off = np.array([0, 1, 4, 7, 8], dtype=np.int64)
     ev = Events(aid=aid, ts=ts, type=typ, sess_off=off, n_aids=10)
-    want = _oracle_rows(ev, cs.ALL_KINDS)
-    b, got = _build(ev, gpu_device)
-    _assert_rows_equal(got, want, cs.ALL_KINDS)
-    assert b.stats()['pairs'] == 2   # only (1,2),(2,1) at ts 100; the third event is > 1 day later
-    empty = Events(aid=aid[:0], ts=ts[:0], type=typ[:0], sess_off=np.zeros(1, dtype=np.int64), n_aids=10)
-    b, got = _build(empty, gpu_device)
-    assert all(len(got[k][0]) == 0 for k in cs.ALL_KINDS)
+    for kinds in (cs.ALL_KINDS, NOFILT):
+        want = _oracle_rows(ev, kinds)
+        b, got = _build(ev, gpu_device, kinds=kinds)
+        _assert_rows_equal(got, want, kinds)
+        assert b.stats()['pairs'] == 2   # only (1,2),(2,1) at ts 100; the third event is > 1 day later
+        empty = Events(aid=aid[:0], ts=ts[:0], type=typ[:0], sess_off=np.zeros(1, dtype=np.int64), n_aids=10)
+        b, got = _build(empty, gpu_device, kinds=kinds)
+        assert all(len(got[k][0]) == 0 for k in kinds)
 
 
 def test_multi_gpu_exchange_roundtrip(gpu_device):
@@ -387,11 +406,11 @@ def test_export_all_equals_per_owner_export(gpu_device):
 
 
 def test_randomized_small_configurations_vs_python_oracle(gpu_device):
-    """40 tiny adversarial streams (few aids -> heavy repeats and ties, equal timestamps, gaps right at the
+    """60 tiny adversarial streams (few aids -> heavy repeats and ties, equal timestamps, gaps right at the
     threshold, window / k sweeps) against the literal pure-Python transcription of SPEC-COVIS."""
     rng = np.random.default_rng(2024)
-    kinds = cs.ALL_KINDS
-    for trial in range(40):
+    for trial in range(60):
+        kinds = cs.ALL_KINDS if trial % 3 == 0 else NOFILT      # class-sorted K1 / fused K1
         n_aids = int(rng.choice([2, 3, 5, 9, 40]))
         S = int(rng.integers(1, 60))
         window = int(rng.choice([2, 3, 7, 16, 30, 32]))
@@ -411,7 +430,8 @@ def test_randomized_small_configurations_vs_python_oracle(gpu_device):
         sp = co.CovisSpec(window=window, max_gap=gap, kinds=kinds)
         want_pairs = co.covis_pairs_python(ev.aid, ev.ts, ev.type, ev.sess_off, sp)
         want = {kd: co.topk_rows(*co.pairs_dict_to_arrays(want_pairs[kd]), k=k) for kd in kinds}
-        _, got = _build(ev, gpu_device, kinds=kinds, k=k, window=window, max_gap=gap, chunks=int(rng.integers(1, 4)))
+        options = {'fast_path': 0} if trial % 3 == 2 else None
+        _, got = _build(ev, gpu_device, kinds=kinds, k=k, window=window, max_gap=gap, chunks=int(rng.integers(1, 4)), options=options)
         try:
             _assert_rows_equal(got, want, kinds)
         except AssertionError as e:
