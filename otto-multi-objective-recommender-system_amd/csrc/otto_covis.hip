@@ -755,6 +755,24 @@ struct BinRuns {     // runs of aid x if it falls in bin `bin`
     }
 };
 
+struct ItemAny {     // 1 if aid x has work items in this bin
+    ItemCount f;
+    __device__ uint64_t operator()(int64_t x) const { return f(x) ? 1ull : 0ull; }
+};
+
+// Processing order of the L bin: the first partition of every heavy aid ("pilot"), then all other partitions. The
+// pilots leave their top-k threshold in tau[x], which lets the aid's other partitions finish in one table pass.
+__global__ void k_fill_order(ItemCount f, uint32_t n_aids, const uint64_t* item_start, const uint64_t* aid_rank,
+                             uint64_t n_pilots, uint32_t* order) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n_aids) return;
+    const uint64_t c = f((int64_t)x);
+    if (!c) return;
+    const uint64_t s = item_start[x], r = aid_rank[x];
+    order[r] = (uint32_t)s;
+    for (uint64_t p = 1; p < c; ++p) order[n_pilots + s + p - r - 1] = (uint32_t)(s + p);
+}
+
 // item = x | part << 26 | log2R << 50
 __global__ void k_fill_items(ItemCount f, uint32_t n_aids, const uint64_t* item_start, uint64_t* items) {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -780,6 +798,7 @@ constexpr int PART_LDS_LOG2R = 12;      // partitions whose histogram / cursors 
 
 struct ReduceArgs {
     const uint64_t* items;
+    const uint32_t* order;         // processing order (dequeue index -> item index), null = identity
     uint32_t n_items;
     const uint64_t* cnt64;         // [n_aids] runs << 36 | records
     const uint64_t* run_start;     // [n_aids+1]
@@ -805,8 +824,13 @@ struct ReduceArgs {
     uint8_t* boost;
     uint32_t* ovf_count;
     uint32_t* work_counter;
+    uint64_t* tau_w;               // [PK][n_aids] threshold guess of a heavy aid's partitions: a lower bound of the 32nd
+    uint32_t* tau_y;               //   best key of a partition already reduced (0 = none yet); tau_y only for GROUP_TIME
     uint32_t l_cap;                // records per L partition the item lists were sized for
     int debug_skip;                // diagnostics only (wrong results): 1 skip gather, 2 skip top-k, 4 skip table init
+#ifdef OTTO_PHASE_PROF
+    unsigned long long* prof;      // [8] summed shader-clock ticks of thread 0 per phase
+#endif
 };
 
 // candidate keys and the wave-level top-k primitives live in topk.h; the covisitation-specific key encodings:
@@ -816,6 +840,8 @@ __device__ __forceinline__ uint64_t kweight(KeyN k) { return (k.c >> REC_AID_BIT
 __device__ __forceinline__ uint64_t kweight(KeyW k) { return k.w; }
 __device__ __forceinline__ uint32_t kaid(KeyN k) { return REC_AID_MASK - (uint32_t)(k.c & REC_AID_MASK); }
 __device__ __forceinline__ uint32_t kaid(KeyW k) { return k.y; }
+__device__ __forceinline__ void ktau_store(KeyN k, uint64_t* w, uint32_t*, size_t o) { w[o] = k.c; }
+__device__ __forceinline__ void ktau_store(KeyW k, uint64_t* w, uint32_t* y, size_t o) { w[o] = k.w; y[o] = k.y; }
 
 // NK independent 64-lane sorts, networks interleaved stage by stage (NK dependency chains in flight)
 template <int NK, typename K>
@@ -1091,6 +1117,11 @@ struct ItemDesc {      // everything a workgroup needs about its item, fetched o
     uint64_t ps, pe;   // bucket range (partitioned heavy aids)
 };
 
+#ifdef OTTO_PHASE_PROF
+#define OTTO_PH(i) do { if (threadIdx.x == 0) { const unsigned long long _t = clock64(); ph[i] += _t - ph_t; ph_t = _t; } } while (0)
+#else
+#define OTTO_PH(i) do {} while (0)
+#endif
 template <int LOG2T, int THREADS, int GROUP, bool PACKED, int MINW, int GU>
 __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     constexpr int T = 1 << LOG2T;
@@ -1117,12 +1148,15 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
 
     const int wid = threadIdx.x >> 6;
     const unsigned lane = lane_id();
+#ifdef OTTO_PHASE_PROF
+    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = clock64();
+#endif
 
     // ---- item pipeline: (index, item word, run range, bucket range) of the NEXT item are fetched while the
     //      current one is reduced, so the dependent loads index -> item -> run_start are off the critical path
     auto fetch_item = [&](uint32_t idx, ItemDesc& d) {     // stage 1: item word
-        d.it = idx;
-        d.item = idx < a.n_items ? a.items[idx] : 0ull;
+        d.it = (a.order && idx < a.n_items) ? a.order[idx] : idx;
+        d.item = idx < a.n_items ? a.items[d.it] : 0ull;
     };
     auto fetch_ranges = [&](ItemDesc& d) {                 // stage 2: ranges (needs the item word)
         d.rb = d.re = d.ps = d.pe = 0;
@@ -1135,11 +1169,27 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     };
     ItemDesc cur, nx;
     uint32_t idx_next = 0, idx_far = 0;   // DYNAMIC, thread 0: dequeued indices of the next two items
+    // Items are reserved DQ at a time (same-address atomics retire at ~90 M/s: one per item would cost 5 ms for the M
+    // bin alone); the next chunk is requested when the current one is opened, so its latency is never waited for.
+    constexpr uint32_t DQ = 4;
+    uint32_t pool = 0, pool_end = 0, pool_next = 0;
+    auto take = [&]() {
+        const uint32_t r = pool++;
+        if (pool == pool_end) {
+            pool = pool_next;
+            pool_end = pool + DQ;
+            pool_next = atomicAdd(a.work_counter, DQ);
+        }
+        return r;
+    };
     if (DYNAMIC) {
         if (threadIdx.x == 0) {
-            const uint32_t i0 = atomicAdd(a.work_counter, 1u);
-            idx_next = atomicAdd(a.work_counter, 1u);
-            idx_far = atomicAdd(a.work_counter, 1u);
+            pool = atomicAdd(a.work_counter, 2 * DQ);
+            pool_end = pool + DQ;
+            pool_next = pool + DQ;
+            const uint32_t i0 = take();
+            idx_next = take();
+            idx_far = take();
             fetch_item(i0, cur);
             fetch_ranges(cur);
             s_cur = cur;
@@ -1155,6 +1205,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             cur = s_cur;
         }
         if (cur.it >= a.n_items) break;
+        OTTO_PH(0);
         const uint32_t it = cur.it;
         // stage 1 of the next item
         if (DYNAMIC) {
@@ -1169,6 +1220,21 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         const uint32_t pmask = (1u << lgR) - 1u;
         const int pshift = 32 - LOG2T - lgR;
 
+        // Partitions of one heavy aid are equal-probability hash samples of its pairs, so their top-k thresholds
+        // agree closely: a partition reduced earlier leaves a lower bound of its 32nd best key in tau[x]; every key
+        // above that guess is collected in ONE pass over the table and, if at least k were found (and the list did
+        // not overflow), the exact top-k is the sorted list -- no lane-bests, no block-wide selection, no second pass.
+        // Any guess is safe: too few / too many candidates fall back to the two-pass path below.
+        K guess[PKD];
+        const bool use_guess = NW > 1 && lgR > 0 && a.tau_w != nullptr;
+#pragma unroll
+        for (int j = 0; j < PKD; ++j) {
+            kclear(guess[j]);
+            if (use_guess && j < a.nk) {
+                const size_t o = (size_t)j * a.n_aids + x;
+                kload(guess[j], a.tau_w[o], WIDE ? a.tau_y[o] : 0u);
+            }
+        }
         if (!(a.debug_skip & 4)) {
             for (int i = threadIdx.x; i < T; i += THREADS) {
                 if (PACKED) {
@@ -1181,6 +1247,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         }
         if (threadIdx.x == 0) s_ovf = 0;
         __syncthreads();
+        OTTO_PH(1);
 
         // one record into the table; `e` = time extra (GROUP_TIME only)
         auto insert = [&](uint32_t rc, uint32_t h, uint32_t e) {
@@ -1279,16 +1346,17 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         } else if (lgR > 0 && a.pstart) {
             // heavy aid, records already bucketed by hash partition: contiguous coalesced reads
             const uint64_t ps = cur.ps, pe = cur.pe;
-            for (uint64_t i0 = ps + threadIdx.x; i0 < pe; i0 += 4 * THREADS) {
-                uint32_t rc[4], e[4];
+            constexpr int BU = GROUP == OTTO_COVIS_GROUP_TIME ? 4 : 6;     // l_cap = 6 * 1024: one round trip per partition
+            for (uint64_t i0 = ps + threadIdx.x; i0 < pe; i0 += BU * THREADS) {
+                uint32_t rc[BU], e[BU];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < BU; ++u) {
                     const uint64_t i = i0 + (uint64_t)u * THREADS;
                     rc[u] = i < pe ? a.prec[i] : KEY_EMPTY;
                     e[u] = (GROUP == OTTO_COVIS_GROUP_TIME && i < pe) ? a.ptw[i] : 0u;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < BU; ++u)
                     if (rc[u] != KEY_EMPTY) insert(rc[u], rec_hash(rc[u]), e[u]);
                 if (s_ovf) break;
             }
@@ -1301,9 +1369,61 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         }
         // stage 2 of the next item (its item word has long arrived)
         if (!DYNAMIC || threadIdx.x == 0) fetch_ranges(nx);
+        OTTO_PH(2);
         __syncthreads();
+        OTTO_PH(3);
         const bool ovf = s_ovf != 0;
-        if (a.debug_skip & 2) {
+        bool fast_done = false;
+        if (NW > 1 && use_guess && !ovf && !(a.debug_skip & 2)) {
+            constexpr int MPLG = T / THREADS;
+            bool gv = true;
+#pragma unroll
+            for (int j = 0; j < PKD; ++j)
+                if (j < a.nk && !kvalid(guess[j])) gv = false;
+            if (gv) {                                    // uniform: every thread loaded the same words
+                if (threadIdx.x < PK) s_nex[threadIdx.x] = 0;
+                if (threadIdx.x == 0) s_more = 0;
+                __syncthreads();
+#pragma unroll 2
+                for (int q = 0; q < MPLG; ++q) {
+                    K kk[PKD];
+                    slot_keys(q * THREADS + threadIdx.x, kk);
+#pragma unroll
+                    for (int j = 0; j < PKD; ++j) {
+                        if (j < a.nk && kvalid(kk[j]) && kbetter(kk[j], guess[j])) {
+                            const uint32_t pos = atomicAdd(&s_nex[j], 1u);
+                            if (pos < (uint32_t)EXCAP) kstore(kk[j], &s_exw[j][pos], &s_exy[0][WIDE ? pos : 0]);
+                            else s_more = 1;
+                        }
+                    }
+                }
+                __syncthreads();
+                bool ok = s_more == 0;
+#pragma unroll
+                for (int j = 0; j < PKD; ++j)
+                    if (j < a.nk && s_nex[j] < (uint32_t)a.k) ok = false;
+#ifdef OTTO_PHASE_PROF
+                if (threadIdx.x == 0) { ph[8]++; if (ok) ph[9]++; else if (s_more) ph[11]++; else ph[10]++; }
+#endif
+                if (ok) {
+                    if (wid < a.nk && wid < PKD) {
+                        const uint32_t n = s_nex[wid];
+                        K cand;
+                        kclear(cand);
+                        if (lane < n) kload(cand, s_exw[wid][lane], s_exy[0][WIDE ? lane : 0]);
+                        wave_bitonic_sort_desc(cand);
+                        emit(wid, cand);
+                        if (n >= 32u && lane == 31u) {
+                            ktau_store(cand, a.tau_w, a.tau_y, (size_t)wid * a.n_aids + x);
+                        }
+                    }
+                    fast_done = true;
+                }
+                __syncthreads();                         // lists are reused by the two-pass path / the next item
+            }
+        }
+        OTTO_PH(7);
+        if (fast_done || (a.debug_skip & 2)) {
         } else if (ovf) {
             // LDS table full: ask the host to redo this aid with twice the partitions
             if (threadIdx.x == 0) {
@@ -1374,6 +1494,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 if (threadIdx.x < PK) s_nex[threadIdx.x] = 0;
                 if (threadIdx.x == 0) s_more = 0;
                 __syncthreads();
+                OTTO_PH(4);
                 K best;
                 kclear(best);
                 const bool merger = wid < a.nk && wid < PKD;      // wave j finishes kind j (nk <= PK <= NW)
@@ -1382,11 +1503,14 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
 #pragma unroll
                     for (int q = 0; q < NW; ++q)
                         kload(lbs[q], s_lbw[wid][q * 64 + lane], s_lby[0][WIDE ? q * 64 + lane : 0]);
-                    wave_topk_select<NW, K>(lbs, a.k, best);
+                    // with threshold guessing on, keep the 32 best lane-bests sorted: lane 31 ends up a lower bound of the
+                    // partition's 32nd best key = the guess for the aid's other partitions
+                    wave_topk_select<NW, K>(lbs, use_guess ? MAX_K : a.k, best);
                     const K thr = kshfl(best, a.k - 1);
                     if (lane == 0) kstore(thr, &s_thrw[wid], &s_thry[wid]);
                 }
                 for (;;) {
+                    OTTO_PH(5);
                     __syncthreads();
                     K thr[PKD];
 #pragma unroll
@@ -1409,6 +1533,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                         }
                     }
                     __syncthreads();
+                    OTTO_PH(6);
                     const bool more = s_more != 0;
                     if (merger) {
                         const uint32_t n = s_nex[wid] < (uint32_t)EXCAP ? s_nex[wid] : (uint32_t)EXCAP;
@@ -1428,7 +1553,13 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                     if (threadIdx.x < PK) s_nex[threadIdx.x] = 0;
                     if (threadIdx.x == 0) s_more = 0;
                 }
-                if (merger) emit(wid, best);
+                if (merger) {
+                    emit(wid, best);
+                    if (use_guess && lane == 31u && kvalid(best)) {
+                        ktau_store(best, a.tau_w, a.tau_y, (size_t)wid * a.n_aids + x);
+                    }
+                }
+                OTTO_PH(7);
             }
         }
         // ---- hand the prefetched next item over ----
@@ -1437,12 +1568,16 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             if (threadIdx.x == 0) {
                 s_cur = nx;
                 idx_next = idx_far;                                   // dequeued one iteration ago
-                idx_far = atomicAdd(a.work_counter, 1u);              // consumed one iteration from now
+                idx_far = take();                                     // consumed one iteration from now
             }
         } else {
             cur = nx;
         }
     }
+#ifdef OTTO_PHASE_PROF
+    if (threadIdx.x == 0 && a.prof)
+        for (int i = 0; i < 12; ++i) atomicAdd(&a.prof[i], ph[i]);
+#endif
 }
 
 // merge the R partial top-k lists of one heavy aid (item with part == 0 and R > 1): one wave per item
@@ -1658,6 +1793,9 @@ struct otto_covis_ctx {
     int debug_skip = 0;
     // reduce scratch
     DevBuf part_y, part_w;
+    DevBuf lorder, lrank;          // L bin: pilot-first processing order
+    DevBuf tau_w, tau_y;           // threshold guesses of partitioned heavy aids (per reduce pass)
+    int guess = 1;                 // option "guess": single-pass top-k from a sibling partition's threshold
     DevBuf exp_run_pos, exp_rec_pos, exp_totals;
     uint64_t exp_n_runs[64] = {0}, exp_n_recs[64] = {0};
     int exp_planned = 0;
@@ -1706,7 +1844,7 @@ extern "C" void otto_covis_destroy(otto_covis_ctx* c) {
                      &c->cls_pos[0], &c->cls_pos[1], &c->cls_pos[2], &c->cls_pos[3], &c->cls_pos[4], &c->cls_pos[5],
                      &c->sess_list, &c->cls_byte,
                      &c->run_start, &c->run_rank, &c->sorted_desc, &c->item_start, &c->boost, &c->flag, &c->counters,
-                     &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->exp_run_pos, &c->exp_rec_pos, &c->exp_totals,
+                     &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->tau_w, &c->tau_y, &c->lorder, &c->lrank, &c->exp_run_pos, &c->exp_rec_pos, &c->exp_totals,
                      &c->litem_start, &c->chunks, &c->pcount, &c->pcursor, &c->pstart, &c->prec, &c->ptw};
     for (DevBuf* b : all) b->release();
     if (c->ev_ok)
@@ -1878,6 +2016,17 @@ static int build_items(otto_covis_ctx* c, int bin, int only_flagged, hipStream_t
         k_fill_items<<<(n_aids + 255) / 256, 256, 0, s>>>(f, n_aids, c->item_start.as<uint64_t>(), c->items[bin].as<uint64_t>());
         OTTO_HIP(hipGetLastError());
     }
+    if (bin == 2 && total) {
+        OTTO_TRY(c->lrank.ensure((size_t)(n_aids + 1) * 8, 0, s));
+        OTTO_TRY(device_scan(ItemAny{f}, (int64_t)n_aids, c->lrank.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+        uint64_t n_pilots = 0;
+        OTTO_HIP(hipMemcpyAsync(&n_pilots, c->lrank.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
+        OTTO_HIP(hipStreamSynchronize(s));
+        OTTO_TRY(c->lorder.ensure((size_t)total * 4, 0, s));
+        k_fill_order<<<(n_aids + 255) / 256, 256, 0, s>>>(f, n_aids, c->item_start.as<uint64_t>(), c->lrank.as<uint64_t>(), n_pilots,
+                                                          c->lorder.as<uint32_t>());
+        OTTO_HIP(hipGetLastError());
+    }
     if (bin == 2) {
         // heavy aids: first L item of every aid + the work items of the partition pass
         OTTO_TRY(c->litem_start.ensure((size_t)(n_aids + 1) * 8, 0, s));
@@ -1955,9 +2104,22 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
     a.items = c->items[bin].as<uint64_t>();
     a.n_items = (uint32_t)c->n_items[bin];
     if (a.n_items == 0) return 0;
+    a.order = (bin == 2 && c->guess && c->partition) ? c->lorder.as<uint32_t>() : nullptr;
     uint32_t* wc = c->counters.as<uint32_t>() + 1 + bin;
     OTTO_HIP(hipMemsetAsync(wc, 0, 4, s));
     a.work_counter = wc;
+#ifdef OTTO_PHASE_PROF
+    static unsigned long long* d_prof = nullptr;
+    if (!d_prof) OTTO_HIP(hipMalloc(&d_prof, 96));
+    OTTO_HIP(hipMemsetAsync(d_prof, 0, 96, s));
+    a.prof = d_prof;
+    struct ProfPrint { int bin; hipStream_t s; unsigned long long* d; ~ProfPrint() {
+        unsigned long long h[12]; hipStreamSynchronize(s); hipMemcpy(h, d, 96, hipMemcpyDeviceToHost);
+        unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += h[i];
+        fprintf(stderr, "[phase-prof] bin %d:", bin);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " p%d %.1f%%", i, tot ? 100.0 * h[i] / tot : 0.0);
+        fprintf(stderr, "  (ticks %llu) guess: tried %llu ok %llu toofew %llu overflow %llu\n", tot, h[8], h[9], h[10], h[11]); } } prof_print{bin, s, d_prof};
+#endif
     if (bin == 0) {
         uint32_t grid = a.n_items < 256u * 20u ? a.n_items : 256u * 20u;
         tbegin(c, OTTO_COVIS_T_REDUCE_S, s);
@@ -2066,6 +2228,16 @@ extern "C" int otto_covis_finalize(otto_covis_ctx* c, int group, int k, uint32_t
         a.l_cap = c->l_cap;
         a.debug_skip = c->debug_skip;
 
+        if (c->guess && c->partition && c->n_items[2]) {
+            OTTO_TRY(c->tau_w.ensure((size_t)PK * n_aids * 8, 0, s));
+            OTTO_HIP(hipMemsetAsync(c->tau_w.p, 0, (size_t)PK * n_aids * 8, s));
+            a.tau_w = c->tau_w.as<uint64_t>();
+            if (group == OTTO_COVIS_GROUP_TIME) {
+                OTTO_TRY(c->tau_y.ensure((size_t)PK * n_aids * 4, 0, s));
+                OTTO_HIP(hipMemsetAsync(c->tau_y.p, 0, (size_t)PK * n_aids * 4, s));
+                a.tau_y = c->tau_y.as<uint32_t>();
+            }
+        }
         bool first = true;
         for (;;) {
             OTTO_HIP(hipMemsetAsync(c->counters.p, 0, 4, s));
@@ -2108,6 +2280,7 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
         return 0;
     }
     if (strcmp(name, "debug_skip") == 0) { c->debug_skip = (int)value; return 0; }   // timing diagnostics, results invalid
+    if (strcmp(name, "guess") == 0) { c->guess = value != 0; return 0; }           // threshold guessing on/off (A/B)
     if (strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }           // fused in-order expansion on/off (A/B)
     if (strcmp(name, "fast_path") == 0) { c->fast_path = value != 0; return 0; }   // gap-free window kernel on/off (A/B)
     if (strcmp(name, "partition") == 0) {
