@@ -684,6 +684,125 @@ __global__ void k_hist_runs(const uint32_t* run_x, const uint64_t* run_desc, int
     }
 }
 
+// ---- bucketed index: the same (cnt64, run_start, sorted_desc) without one global atomic per run -------------
+// The histogram / scatter pair above pays one returning memory-side atomic and two random 8-byte accesses per run.
+// Here the non-empty runs are first split into buckets of 2^SH consecutive aids (count -> scan -> scatter with one
+// cursor bump per (chunk, bucket)), then one workgroup per bucket counts and places its runs with LDS atomics
+// only; a bucket's slice of run_start / sorted_desc is a window of a few hundred KB, so those writes combine in L2.
+constexpr int BKT_THREADS = 1024;
+constexpr int BKT_CHUNK = 32768;                      // run slots per pass-1 work item
+constexpr int BKT_MAX_NB = 4096;                      // buckets (LDS histogram of pass 1)
+
+struct BktArgs {
+    const uint32_t* run_x;
+    const uint64_t* run_desc;
+    int64_t n_slots;
+    uint32_t n_aids;
+    int sh;                        // aids per bucket = 1 << sh
+    uint32_t nb;
+    uint32_t* bcount;              // [nb] runs per bucket, then the scatter cursors
+    const uint64_t* bstart;        // [nb + 1]
+    uint32_t* tmp_x;               // bucketed runs
+    uint64_t* tmp_desc;
+    uint64_t* cnt64;
+    const uint64_t* run_start;
+    uint64_t* sorted_desc;
+};
+
+template <bool SCATTER>
+__global__ __launch_bounds__(BKT_THREADS) void k_bkt_split(BktArgs a) {
+    __shared__ uint32_t s_cnt[BKT_MAX_NB];
+    __shared__ uint32_t s_base[SCATTER ? BKT_MAX_NB : 1];
+    const int64_t n_chunks = (a.n_slots + BKT_CHUNK - 1) / BKT_CHUNK;
+    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        for (uint32_t b = threadIdx.x; b < a.nb; b += BKT_THREADS) s_cnt[b] = 0;
+        __syncthreads();
+        const int64_t i0 = ch * BKT_CHUNK;
+        constexpr int PER = BKT_CHUNK / BKT_THREADS;
+        uint32_t xs[PER];                    // aid of a non-empty run with a valid aid, else 0xFFFFFFFF
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int64_t i = i0 + (int64_t)u * BKT_THREADS + threadIdx.x;
+            uint32_t x = 0xFFFFFFFFu;
+            if (i < a.n_slots && (a.run_desc[i] & 0xFFull)) x = a.run_x[i];
+            if (x >= a.n_aids) x = 0xFFFFFFFFu;
+            xs[u] = x;
+            if (x != 0xFFFFFFFFu) atomicAdd(&s_cnt[x >> a.sh], 1u);
+        }
+        __syncthreads();
+        if (!SCATTER) {
+            for (uint32_t b = threadIdx.x; b < a.nb; b += BKT_THREADS) {
+                const uint32_t n = s_cnt[b];
+                if (n) atomicAdd(&a.bcount[b], n);
+            }
+        } else {
+            for (uint32_t b = threadIdx.x; b < a.nb; b += BKT_THREADS) {
+                const uint32_t n = s_cnt[b];
+                s_base[b] = n ? atomicAdd(&a.bcount[b], n) : 0u;     // bcount was reset: it is the bucket cursor now
+                s_cnt[b] = 0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                if (xs[u] != 0xFFFFFFFFu) {
+                    const uint32_t b = xs[u] >> a.sh;
+                    const uint64_t pos = a.bstart[b] + s_base[b] + atomicAdd(&s_cnt[b], 1u);
+                    a.tmp_x[pos] = xs[u];
+                    a.tmp_desc[pos] = a.run_desc[i0 + (int64_t)u * BKT_THREADS + threadIdx.x];   // second read: L2 / MALL hit
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// one workgroup per bucket. PLACE = false: cnt64 of the bucket's aids; PLACE = true: sorted_desc.
+template <bool PLACE>
+__global__ __launch_bounds__(BKT_THREADS) void k_bkt_local(BktArgs a) {
+    extern __shared__ unsigned long long s_dyn[];          // [1 << sh]: runs << 36 | records, or start positions
+    uint32_t* s_cur = reinterpret_cast<uint32_t*>(s_dyn + ((size_t)1 << a.sh));   // PLACE: [1 << sh] cursors
+    const uint32_t ab = 1u << a.sh;
+    for (uint32_t b = blockIdx.x; b < a.nb; b += gridDim.x) {
+        const uint32_t x0 = b << a.sh;
+        for (uint32_t i = threadIdx.x; i < ab; i += BKT_THREADS) {
+            if (PLACE) {
+                s_dyn[i] = x0 + i < a.n_aids ? a.run_start[x0 + i] : 0ull;
+                s_cur[i] = 0;
+            } else {
+                s_dyn[i] = 0;
+            }
+        }
+        __syncthreads();
+        const uint64_t e0 = a.bstart[b], e1 = a.bstart[b + 1];
+        for (uint64_t i0 = e0 + threadIdx.x; i0 < e1; i0 += 4 * BKT_THREADS) {
+            uint32_t xl[4];
+            uint64_t d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint64_t i = i0 + (uint64_t)u * BKT_THREADS;
+                d[u] = i < e1 ? a.tmp_desc[i] : 0ull;
+                xl[u] = i < e1 ? a.tmp_x[i] - x0 : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!d[u]) continue;
+                if (PLACE) a.sorted_desc[s_dyn[xl[u]] + atomicAdd(&s_cur[xl[u]], 1u)] = d[u];
+                else atomicAdd(&s_dyn[xl[u]], (1ull << CNT_REC_BITS) | (d[u] & 0xFFull));
+            }
+        }
+        __syncthreads();
+        if (!PLACE)
+            for (uint32_t i = threadIdx.x; i < ab; i += BKT_THREADS)
+                if (x0 + i < a.n_aids) a.cnt64[x0 + i] = s_dyn[i];
+        __syncthreads();
+    }
+}
+
+struct BktCount {
+    const uint32_t* c;
+    __device__ uint64_t operator()(int64_t i) const { return c[i]; }
+};
+
 struct RunCount {
     const uint64_t* cnt64;
     __device__ uint64_t operator()(int64_t x) const { return cnt64[x] >> CNT_REC_BITS; }
@@ -1793,6 +1912,8 @@ struct otto_covis_ctx {
     int debug_skip = 0;
     // reduce scratch
     DevBuf part_y, part_w;
+    DevBuf bcount, bstart, tmp_x, tmp_desc;   // bucketed index
+    int bucket_index = 1;          // option "bucket_index": LDS-atomic index build (0 = global-atomic histogram)
     DevBuf lorder, lrank;          // L bin: pilot-first processing order
     DevBuf tau_w, tau_y;           // threshold guesses of partitioned heavy aids (per reduce pass)
     int guess = 1;                 // option "guess": single-pass top-k from a sibling partition's threshold
@@ -1844,7 +1965,7 @@ extern "C" void otto_covis_destroy(otto_covis_ctx* c) {
                      &c->cls_pos[0], &c->cls_pos[1], &c->cls_pos[2], &c->cls_pos[3], &c->cls_pos[4], &c->cls_pos[5],
                      &c->sess_list, &c->cls_byte,
                      &c->run_start, &c->run_rank, &c->sorted_desc, &c->item_start, &c->boost, &c->flag, &c->counters,
-                     &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->tau_w, &c->tau_y, &c->lorder, &c->lrank, &c->exp_run_pos, &c->exp_rec_pos, &c->exp_totals,
+                     &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->tau_w, &c->tau_y, &c->lorder, &c->lrank, &c->bcount, &c->bstart, &c->tmp_x, &c->tmp_desc, &c->exp_run_pos, &c->exp_rec_pos, &c->exp_totals,
                      &c->litem_start, &c->chunks, &c->pcount, &c->pcursor, &c->pstart, &c->prec, &c->ptw};
     for (DevBuf* b : all) b->release();
     if (c->ev_ok)
@@ -2062,7 +2183,40 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
     OTTO_HIP(hipMemsetAsync(c->boost.p, 0, (size_t)n_aids, s));
     OTTO_HIP(hipMemsetAsync(c->flag.p, 0, (size_t)n_aids * 4, s));
     const int64_t n_slots = (int64_t)c->run_used;
-    if (n_slots) {
+    int aid_bits = 1;
+    while ((1ull << aid_bits) < (uint64_t)n_aids) ++aid_bits;
+    BktArgs ba;
+    memset(&ba, 0, sizeof ba);
+    ba.sh = aid_bits > 22 ? aid_bits - 12 : 10;
+    ba.nb = (uint32_t)(((uint64_t)n_aids + (1ull << ba.sh) - 1) >> ba.sh);
+    const bool bucketed = c->bucket_index && n_slots > 0 && ba.nb <= (uint32_t)BKT_MAX_NB && ba.sh <= 12;   // <= 48 KB of LDS per bucket
+    if (bucketed) {
+        ba.run_x = c->run_x.as<uint32_t>(); ba.run_desc = c->run_desc.as<uint64_t>();
+        ba.n_slots = n_slots; ba.n_aids = n_aids;
+        OTTO_TRY(c->bcount.ensure((size_t)ba.nb * 4, 0, s));
+        OTTO_TRY(c->bstart.ensure((size_t)(ba.nb + 1) * 8, 0, s));
+        OTTO_HIP(hipMemsetAsync(c->bcount.p, 0, (size_t)ba.nb * 4, s));
+        ba.bcount = c->bcount.as<uint32_t>();
+        const int64_t n_chunks = (n_slots + BKT_CHUNK - 1) / BKT_CHUNK;
+        const int sgrid = (int)(n_chunks < 256 * 2 ? n_chunks : 256 * 2);
+        k_bkt_split<false><<<sgrid, BKT_THREADS, 0, s>>>(ba);
+        OTTO_HIP(hipGetLastError());
+        OTTO_TRY(device_scan(BktCount{ba.bcount}, (int64_t)ba.nb, c->bstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+        uint64_t n_runs_b = 0;
+        OTTO_HIP(hipMemcpyAsync(&n_runs_b, c->bstart.as<uint64_t>() + ba.nb, 8, hipMemcpyDeviceToHost, s));
+        OTTO_HIP(hipStreamSynchronize(s));
+        OTTO_TRY(c->tmp_x.ensure((size_t)(n_runs_b ? n_runs_b : 1) * 4, 0, s));
+        OTTO_TRY(c->tmp_desc.ensure((size_t)(n_runs_b ? n_runs_b : 1) * 8, 0, s));
+        OTTO_HIP(hipMemsetAsync(c->bcount.p, 0, (size_t)ba.nb * 4, s));
+        ba.bstart = c->bstart.as<uint64_t>();
+        ba.tmp_x = c->tmp_x.as<uint32_t>(); ba.tmp_desc = c->tmp_desc.as<uint64_t>();
+        k_bkt_split<true><<<sgrid, BKT_THREADS, 0, s>>>(ba);
+        OTTO_HIP(hipGetLastError());
+        ba.cnt64 = c->cnt64.as<uint64_t>();
+        const int lgrid = (int)(ba.nb < 256u * 2u ? ba.nb : 256u * 2u);
+        k_bkt_local<false><<<lgrid, BKT_THREADS, (size_t)8 << ba.sh, s>>>(ba);
+        OTTO_HIP(hipGetLastError());
+    } else if (n_slots) {
         int grid = (int)((n_slots + 255) / 256 < 256 * 32 ? (n_slots + 255) / 256 : 256 * 32);
         k_hist_runs<<<grid, 256, 0, s>>>(c->run_x.as<uint32_t>(), c->run_desc.as<uint64_t>(), n_slots, c->cnt64.as<uint64_t>(),
                                          c->run_rank.as<uint32_t>(), n_aids);
@@ -2078,7 +2232,13 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
     c->n_pairs = tot[0];
     c->n_runs = tot[1];
     OTTO_TRY(c->sorted_desc.ensure((size_t)(c->n_runs ? c->n_runs : 1) * 8, 0, s));
-    if (n_slots) {
+    if (bucketed) {
+        ba.run_start = c->run_start.as<uint64_t>();
+        ba.sorted_desc = c->sorted_desc.as<uint64_t>();
+        const int lgrid = (int)(ba.nb < 256u * 2u ? ba.nb : 256u * 2u);
+        k_bkt_local<true><<<lgrid, BKT_THREADS, (size_t)12 << ba.sh, s>>>(ba);
+        OTTO_HIP(hipGetLastError());
+    } else if (n_slots) {
         int grid = (int)((n_slots + 255) / 256 < 256 * 32 ? (n_slots + 255) / 256 : 256 * 32);
         k_scatter_runs<<<grid, 256, 0, s>>>(c->run_x.as<uint32_t>(), c->run_desc.as<uint64_t>(), c->run_rank.as<uint32_t>(),
                                             n_slots, c->run_start.as<uint64_t>(), c->sorted_desc.as<uint64_t>(), n_aids);
@@ -2280,6 +2440,7 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
         return 0;
     }
     if (strcmp(name, "debug_skip") == 0) { c->debug_skip = (int)value; return 0; }   // timing diagnostics, results invalid
+    if (strcmp(name, "bucket_index") == 0) { c->bucket_index = value != 0; return 0; }
     if (strcmp(name, "guess") == 0) { c->guess = value != 0; return 0; }           // threshold guessing on/off (A/B)
     if (strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }           // fused in-order expansion on/off (A/B)
     if (strcmp(name, "fast_path") == 0) { c->fast_path = value != 0; return 0; }   // gap-free window kernel on/off (A/B)
