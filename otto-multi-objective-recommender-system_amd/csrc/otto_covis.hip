@@ -690,7 +690,7 @@ __global__ void k_hist_runs(const uint32_t* run_x, const uint64_t* run_desc, int
 // cursor bump per (chunk, bucket)), then one workgroup per bucket counts and places its runs with LDS atomics
 // only; a bucket's slice of run_start / sorted_desc is a window of a few hundred KB, so those writes combine in L2.
 constexpr int BKT_THREADS = 1024;
-constexpr int BKT_CHUNK = 32768;                      // run slots per pass-1 work item
+constexpr int BKT_CHUNK = 16384;                      // run slots per pass-1 work item
 constexpr int BKT_MAX_NB = 4096;                      // buckets (LDS histogram of pass 1)
 
 struct BktArgs {
@@ -702,8 +702,7 @@ struct BktArgs {
     uint32_t nb;
     uint32_t* bcount;              // [nb] runs per bucket, then the scatter cursors
     const uint64_t* bstart;        // [nb + 1]
-    uint32_t* tmp_x;               // bucketed runs
-    uint64_t* tmp_desc;
+    ulonglong2* tmp;               // bucketed runs {desc, aid_x}
     uint64_t* cnt64;
     const uint64_t* run_start;
     uint64_t* sorted_desc;
@@ -712,21 +711,27 @@ struct BktArgs {
 template <bool SCATTER>
 __global__ __launch_bounds__(BKT_THREADS) void k_bkt_split(BktArgs a) {
     __shared__ uint32_t s_cnt[BKT_MAX_NB];
-    __shared__ uint32_t s_base[SCATTER ? BKT_MAX_NB : 1];
+    __shared__ uint64_t s_base[SCATTER ? BKT_MAX_NB : 1];      // global position of the chunk's piece of bucket b
     const int64_t n_chunks = (a.n_slots + BKT_CHUNK - 1) / BKT_CHUNK;
+    constexpr int PER = BKT_CHUNK / BKT_THREADS;
     for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
         for (uint32_t b = threadIdx.x; b < a.nb; b += BKT_THREADS) s_cnt[b] = 0;
         __syncthreads();
-        const int64_t i0 = ch * BKT_CHUNK;
-        constexpr int PER = BKT_CHUNK / BKT_THREADS;
+        const int64_t i0 = ch * BKT_CHUNK + threadIdx.x;
         uint32_t xs[PER];                    // aid of a non-empty run with a valid aid, else 0xFFFFFFFF
+        uint64_t ds[SCATTER ? PER : 1];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int64_t i = i0 + (int64_t)u * BKT_THREADS + threadIdx.x;
+            const int64_t i = i0 + (int64_t)u * BKT_THREADS;
             uint32_t x = 0xFFFFFFFFu;
-            if (i < a.n_slots && (a.run_desc[i] & 0xFFull)) x = a.run_x[i];
+            uint64_t d = 0;
+            if (i < a.n_slots) {
+                d = a.run_desc[i];
+                if (d & 0xFFull) x = a.run_x[i];
+            }
             if (x >= a.n_aids) x = 0xFFFFFFFFu;
             xs[u] = x;
+            if (SCATTER) ds[u] = d;
             if (x != 0xFFFFFFFFu) atomicAdd(&s_cnt[x >> a.sh], 1u);
         }
         __syncthreads();
@@ -738,7 +743,7 @@ __global__ __launch_bounds__(BKT_THREADS) void k_bkt_split(BktArgs a) {
         } else {
             for (uint32_t b = threadIdx.x; b < a.nb; b += BKT_THREADS) {
                 const uint32_t n = s_cnt[b];
-                s_base[b] = n ? atomicAdd(&a.bcount[b], n) : 0u;     // bcount was reset: it is the bucket cursor now
+                s_base[b] = n ? a.bstart[b] + atomicAdd(&a.bcount[b], n) : 0ull;     // bcount was reset: it is the bucket cursor now
                 s_cnt[b] = 0;
             }
             __syncthreads();
@@ -746,9 +751,8 @@ __global__ __launch_bounds__(BKT_THREADS) void k_bkt_split(BktArgs a) {
             for (int u = 0; u < PER; ++u) {
                 if (xs[u] != 0xFFFFFFFFu) {
                     const uint32_t b = xs[u] >> a.sh;
-                    const uint64_t pos = a.bstart[b] + s_base[b] + atomicAdd(&s_cnt[b], 1u);
-                    a.tmp_x[pos] = xs[u];
-                    a.tmp_desc[pos] = a.run_desc[i0 + (int64_t)u * BKT_THREADS + threadIdx.x];   // second read: L2 / MALL hit
+                    const uint64_t pos = s_base[b] + atomicAdd(&s_cnt[b], 1u);
+                    a.tmp[pos] = make_ulonglong2(ds[u], (unsigned long long)xs[u]);     // one 16-byte store per run
                 }
             }
         }
@@ -780,8 +784,10 @@ __global__ __launch_bounds__(BKT_THREADS) void k_bkt_local(BktArgs a) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint64_t i = i0 + (uint64_t)u * BKT_THREADS;
-                d[u] = i < e1 ? a.tmp_desc[i] : 0ull;
-                xl[u] = i < e1 ? a.tmp_x[i] - x0 : 0u;
+                ulonglong2 r = make_ulonglong2(0ull, 0ull);
+                if (i < e1) r = a.tmp[i];
+                d[u] = r.x;
+                xl[u] = (uint32_t)r.y - x0;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1912,7 +1918,7 @@ struct otto_covis_ctx {
     int debug_skip = 0;
     // reduce scratch
     DevBuf part_y, part_w;
-    DevBuf bcount, bstart, tmp_x, tmp_desc;   // bucketed index
+    DevBuf bcount, bstart, tmp_runs;          // bucketed index
     int bucket_index = 1;          // option "bucket_index": LDS-atomic index build (0 = global-atomic histogram)
     DevBuf lorder, lrank;          // L bin: pilot-first processing order
     DevBuf tau_w, tau_y;           // threshold guesses of partitioned heavy aids (per reduce pass)
@@ -1965,7 +1971,7 @@ extern "C" void otto_covis_destroy(otto_covis_ctx* c) {
                      &c->cls_pos[0], &c->cls_pos[1], &c->cls_pos[2], &c->cls_pos[3], &c->cls_pos[4], &c->cls_pos[5],
                      &c->sess_list, &c->cls_byte,
                      &c->run_start, &c->run_rank, &c->sorted_desc, &c->item_start, &c->boost, &c->flag, &c->counters,
-                     &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->tau_w, &c->tau_y, &c->lorder, &c->lrank, &c->bcount, &c->bstart, &c->tmp_x, &c->tmp_desc, &c->exp_run_pos, &c->exp_rec_pos, &c->exp_totals,
+                     &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->tau_w, &c->tau_y, &c->lorder, &c->lrank, &c->bcount, &c->bstart, &c->tmp_runs, &c->exp_run_pos, &c->exp_rec_pos, &c->exp_totals,
                      &c->litem_start, &c->chunks, &c->pcount, &c->pcursor, &c->pstart, &c->prec, &c->ptw};
     for (DevBuf* b : all) b->release();
     if (c->ev_ok)
@@ -2205,11 +2211,10 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
         uint64_t n_runs_b = 0;
         OTTO_HIP(hipMemcpyAsync(&n_runs_b, c->bstart.as<uint64_t>() + ba.nb, 8, hipMemcpyDeviceToHost, s));
         OTTO_HIP(hipStreamSynchronize(s));
-        OTTO_TRY(c->tmp_x.ensure((size_t)(n_runs_b ? n_runs_b : 1) * 4, 0, s));
-        OTTO_TRY(c->tmp_desc.ensure((size_t)(n_runs_b ? n_runs_b : 1) * 8, 0, s));
+        OTTO_TRY(c->tmp_runs.ensure((size_t)(n_runs_b ? n_runs_b : 1) * 16, 0, s));
         OTTO_HIP(hipMemsetAsync(c->bcount.p, 0, (size_t)ba.nb * 4, s));
         ba.bstart = c->bstart.as<uint64_t>();
-        ba.tmp_x = c->tmp_x.as<uint32_t>(); ba.tmp_desc = c->tmp_desc.as<uint64_t>();
+        ba.tmp = c->tmp_runs.as<ulonglong2>();
         k_bkt_split<true><<<sgrid, BKT_THREADS, 0, s>>>(ba);
         OTTO_HIP(hipGetLastError());
         ba.cnt64 = c->cnt64.as<uint64_t>();
