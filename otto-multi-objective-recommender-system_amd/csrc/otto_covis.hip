@@ -1269,6 +1269,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     __shared__ uint32_t s_nex[PK];
     __shared__ uint32_t s_more;
     __shared__ uint32_t s_ovf;
+    __shared__ uint16_t s_list[NW == 1 ? 64 : 1];                              // one-wave bins: compacted valid slots
     __shared__ ItemDesc s_cur;
 
     const int wid = threadIdx.x >> 6;
@@ -1559,6 +1560,36 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         } else {
             constexpr int MPL = T / THREADS;
             static_assert(MPL <= 32, "consumed-slot bitmask is 32 bits");
+            // One-wave bins: most small aids have at most 64 distinct partners. Then the valid slots are compacted to one
+            // per lane (ballot ranks), each lane builds its keys once and ONE sorting network per kind is the whole top-k:
+            // no lane-bests, no threshold rounds over the table.
+            bool compact_done = false;
+            if (NW == 1) {
+                uint32_t nvalid = 0;
+#pragma unroll
+                for (int q = 0; q < MPL; ++q) {
+                    const int i = q * THREADS + threadIdx.x;
+                    const bool v = PACKED ? (s_tab[PACKED ? i : 0] != TAB_EMPTY) : (s_key[PACKED ? 0 : i] != KEY_EMPTY);
+                    const uint64_t m = __ballot(v);
+                    const uint32_t pos = nvalid + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (v && pos < 64u) s_list[pos] = (uint16_t)i;
+                    nvalid += (uint32_t)__popcll(m);
+                }
+                if (nvalid <= 64u) {
+                    __syncthreads();
+                    K bests[PKD];
+#pragma unroll
+                    for (int j = 0; j < PKD; ++j) kclear(bests[j]);
+                    if (lane < nvalid) slot_keys((int)s_list[lane], bests);
+                    wave_bitonic_sort_multi<PKD, K>(bests);
+#pragma unroll
+                    for (int j = 0; j < PKD; ++j)
+                        if (j < a.nk) emit(j, bests[j]);
+                    compact_done = true;
+                    __syncthreads();
+                }
+            }
+            if (!compact_done) {
             // Candidate keys are NOT cached in registers (3 kinds x MPL keys would cost ~100 VGPRs and halve the
             // resident workgroups): they are recomputed from the LDS table when needed (one read + a few 32-bit
             // ops), with a per-kind bitmask of the slots of this lane that are already in a list.
@@ -1586,28 +1617,41 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
 #pragma unroll
                 for (int j = 0; j < PKD; ++j) bests[j] = lb[j];
                 wave_bitonic_sort_multi<PKD, K>(bests);
+                // one rescan of the lane's slots serves ALL kinds: per kind the lane's best remaining key above the
+                // kind's k-th entry; repeat while any kind still found one (rounds = max over kinds, not the sum)
+                for (;;) {
+                    K thr[PKD], cb[PKD];
+                    int ci[PKD];
 #pragma unroll
-                for (int j = 0; j < PKD; ++j) {
-                    if (j >= a.nk) continue;
-                    for (;;) {
-                        const K thr = kshfl(bests[j], a.k - 1);
-                        K cb;
-                        kclear(cb);
-                        int ci = -1;
-#pragma unroll 1
-                        for (int q = 0; q < MPL; ++q) {
-                            if ((done[j] >> q) & 1u) continue;
-                            K kk[PKD];
-                            slot_keys(q * THREADS + threadIdx.x, kk);
-                            if (kvalid(kk[j]) && (ci < 0 || kbetter(kk[j], cb))) { cb = kk[j]; ci = q; }
-                        }
-                        const bool qual = ci >= 0 && kbetter(cb, thr);
-                        if (__ballot(qual) == 0) break;
-                        if (qual) done[j] |= 1u << ci; else kclear(cb);
-                        wave_topk_push(bests[j], cb, a.k);
+                    for (int j = 0; j < PKD; ++j) {
+                        thr[j] = kshfl(bests[j], a.k - 1);
+                        kclear(cb[j]);
+                        ci[j] = -1;
                     }
-                    emit(j, bests[j]);
+#pragma unroll 1
+                    for (int q = 0; q < MPL; ++q) {
+                        K kk[PKD];
+                        slot_keys(q * THREADS + threadIdx.x, kk);
+#pragma unroll
+                        for (int j = 0; j < PKD; ++j)
+                            if (!((done[j] >> q) & 1u) && kvalid(kk[j]) && kbetter(kk[j], thr[j]) &&
+                                (ci[j] < 0 || kbetter(kk[j], cb[j]))) { cb[j] = kk[j]; ci[j] = q; }
+                    }
+                    bool any = false;
+#pragma unroll
+                    for (int j = 0; j < PKD; ++j) {
+                        if (j >= a.nk) continue;
+                        const bool qual = ci[j] >= 0;
+                        if (__ballot(qual) == 0) continue;
+                        any = true;
+                        if (qual) done[j] |= 1u << ci[j];
+                        wave_topk_push(bests[j], cb[j], a.k);
+                    }
+                    if (!any) break;
                 }
+#pragma unroll
+                for (int j = 0; j < PKD; ++j)
+                    if (j < a.nk) emit(j, bests[j]);
             } else {
                 // ---- block-wide: ONE sort per kind. P1 every lane: lane-best to LDS.
                 //      P2 wave j: top-k of the THREADS lane-bests, publish the k-th as threshold.
@@ -1685,6 +1729,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                     }
                 }
                 OTTO_PH(7);
+            }
             }
         }
         // ---- hand the prefetched next item over ----
