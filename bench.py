@@ -55,8 +55,9 @@ def algorithmic_bytes(st, k, nk):
         # write one 4-byte record per pair and one (aid_x u32, descriptor u64) per window event
         'expand': 9 * Et + 24 * S + 4 * P + 12 * Et,
     }
-    # index: read (aid_x u32, descriptor u64) per window event twice (histogram, scatter), write one descriptor per run
-    out['index'] = 2 * 12 * Et + 8 * st['runs']
+    # index: read (aid_x u32, descriptor u64) per window event once, write one descriptor per run grouped by aid_x (the
+    # bucket split's intermediate copy and the second reads are overhead, not algorithmic)
+    out['index'] = 12 * Et + 8 * st['runs']
     # partition: the heavy aids' records are read once and written once into buckets (the count pass and the
     # second read of the scatter pass are overhead, not algorithmic), plus their run descriptors
     out['partition'] = 8 * st['pairs_l'] + 8 * st['runs_l']
@@ -68,7 +69,7 @@ def algorithmic_bytes(st, k, nk):
     return out
 
 
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'round1', 'traffic_v1.json')
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'round1', 'traffic_v2.json')
 
 
 def pmc_traffic(substrings, full_otto):
@@ -240,12 +241,13 @@ def main():
         cand = {n: kernel_ms.get(n, 0.0) for n in ('expand', 'index', 'partition', 'reduce_s', 'reduce_m', 'reduce_l')}
         dom = max(cand, key=cand.get)
         full_otto = world == 1 and a.sessions == 14_571_582 and a.k == 20
-        ksub = {'expand': ('k_expand', 'k_fill_classes'), 'index': ('k_hist_runs', 'k_scatter_runs'), 'partition': ('k_partition',),
+        ksub = {'expand': ('k_expand',), 'index': ('k_bkt_',), 'partition': ('k_partition',),
                 'reduce_s': ('k_reduce<9,',), 'reduce_m': ('k_reduce<12,',), 'reduce_l': ('k_reduce<13,',)}
-        knames = {'expand': 'k_expand<G,..> + k_expand_fast<G,..> (G = 8, 16, 32; general and gap-free windows) + k_fill_classes',
+        knames = {'expand': 'k_expand_fused<false> (windows of 8 / 16 / 32 lanes, general and gap-free, one launch)',
                   'reduce_s': 'k_reduce<9, 64, 0, true, 5, 8>', 'reduce_m': 'k_reduce<12, 256, 0, true, 4, 4>',
                   'reduce_l': 'k_reduce<13, 1024, 0, false, 4, 2>',
-                  'partition': 'k_partition<false> + k_partition<true>', 'index': 'k_hist_runs + k_scatter_runs + scans'}
+                  'partition': 'k_partition<false> + k_partition<true>',
+                  'index': 'k_bkt_split<false/true> + k_bkt_local<false/true> + scans'}
         result = {
             'metric': 'aid-pairs/sec covisitation build',
             'value': round(pairs * a.steps / dt, 1),

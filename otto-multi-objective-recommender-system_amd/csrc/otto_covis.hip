@@ -541,26 +541,32 @@ __device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, 
     wave_lds_sync();
     const uint64_t same64 = (uint64_t)same << w0;
     const uint64_t samelow64 = same64 & lw64;
+    const uint32_t nlim = act ? (uint32_t)n : 0u;
     uint32_t done = 0;
     uint4 e = evw[0];
     if (a.debug & 2) nmax = 0;
+    // Predicates are kept as wave masks (v_cmp writes them, s_and combines them, exec takes them): the whole wave is
+    // active here, so a mask IS the ballot -- no select/compare round trip per ballot.
+    constexpr int NE = 33, EQ = 32, ULT = 36, ULE = 37;
     for (int i = 0; i < nmax; ++i) {
         const uint4 en = evw[(i + 1) & (G - 1)];                // next row in flight
         const uint32_t dA = e.y - (uint32_t)t, dB = (uint32_t)t - e.y;
         const uint32_t ad = dA < dB ? dA : dB;                    // |dt| (|dt| < 2^31)
-        const bool valid = act && i < n && e.x != aid && ad <= (uint32_t)a.max_gap;
-        const uint64_t V = __ballot(valid);
-        const bool mine = (V & same64) != 0;
-        const uint32_t ci = e.z & 31u;
-        const bool seen = (done >> ci) & 1u;
-        const bool emit = valid && !seen && (V & samelow64) == 0;
-        const uint64_t D = __ballot(rep && seen);
-        const uint64_t E = __ballot(emit);
-        if (mine) done |= 1u << ci;
-        if (emit && !(a.debug & 1)) {
-            const uint32_t o = (e.z >> 5) + (uint32_t)__popcll(D & win64) + (uint32_t)__popcll(E & lw64);
-            recp[o] = word;
-            if (TIME) twp[o] = e.w;
+        const uint64_t V = __builtin_amdgcn_uicmp((uint32_t)i, nlim, ULT) & __builtin_amdgcn_uicmp(e.x, aid, NE) &
+                           __builtin_amdgcn_uicmp(ad, (uint32_t)a.max_gap, ULE);        // valid pairs (i, lane)
+        if (V != 0) {                                             // uniform: rows without any valid pair cost nothing more
+            const uint32_t bit = 1u << (e.z & 31u);               // x class of this row
+            const uint64_t S = __builtin_amdgcn_uicmp(done & bit, 0u, NE);              // my class already took (x class, me)
+            const uint64_t M = __builtin_amdgcn_uicmpl(V & same64, 0ull, NE);           // my class meets this row
+            const uint64_t F = __builtin_amdgcn_uicmpl(V & samelow64, 0ull, EQ);        // no lower lane of my class is valid
+            const uint64_t E = V & ~S & F;                                              // lanes that emit
+            const uint64_t D = rep64 & S;                                               // column classes already in the row
+            if (__builtin_amdgcn_inverse_ballot_w64(M)) done |= bit;
+            if (__builtin_amdgcn_inverse_ballot_w64(E) && !(a.debug & 1)) {
+                const uint32_t o = (e.z >> 5) + (uint32_t)__popcll(D & win64) + (uint32_t)__popcll(E & lw64);
+                recp[o] = word;
+                if (TIME) twp[o] = e.w;
+            }
         }
         e = en;
     }
