@@ -840,12 +840,26 @@ constexpr int S_LOG2T = 9, S_THREADS = 64, S_CAP = 384;
 constexpr int M_LOG2T = 12, M_THREADS = 256, M_CAP = 3072;
 constexpr int L_LOG2T = 13, L_THREADS = 1024, L_CAP = 6144;
 
-__device__ __forceinline__ int l_log2r(uint64_t n, int boost, uint32_t l_cap) {
-    uint64_t parts = (n + l_cap - 1) / l_cap;
+// Heavy aids come in two table layouts. An (x, y) pair gains at most one record per session that holds x, so a
+// counter of aid x never exceeds runs(x): heavy aids with fewer than 4096 runs (82 % of the heavy pair mass at OTTO
+// shape) are safe in the PACKED layout (12-bit counters) -- twice the slots in the same LDS (2^14), partitions of
+// twice the records, half the work items. The others, and the time group, keep the wide layout (2^13 slots).
+constexpr int LP_LOG2T = 14;
+constexpr uint64_t PACKED_MAX_RUNS = 4096;
+__device__ __forceinline__ bool heavy_packed(uint64_t c64, int allow_packed) {
+    return allow_packed && (c64 >> CNT_REC_BITS) < PACKED_MAX_RUNS;
+}
+__device__ __forceinline__ int heavy_log2t(uint64_t c64, int allow_packed) { return heavy_packed(c64, allow_packed) ? LP_LOG2T : L_LOG2T; }
+
+// log2 of the number of hash partitions of a heavy aid (records n, layout from its run count)
+__device__ __forceinline__ int l_log2r(uint64_t c64, int boost, uint32_t l_cap, int allow_packed) {
+    const uint64_t n = c64 & CNT_REC_MASK;
+    const uint64_t cap = heavy_packed(c64, allow_packed) ? 2ull * l_cap : (uint64_t)l_cap;
+    uint64_t parts = (n + cap - 1) / cap;
     int lg = 0;
     while ((1ull << lg) < parts) ++lg;
     lg += boost;
-    const int maxlg = 32 - L_LOG2T;
+    const int maxlg = 32 - heavy_log2t(c64, allow_packed);
     return lg > maxlg ? maxlg : lg;
 }
 
@@ -856,13 +870,17 @@ struct ItemCount {   // number of work items aid x contributes to bin `bin`
     int bin;
     int only_flagged;
     uint32_t l_cap;
+    int allow_packed;
+    int mode;                      // bin 2 only: -1 every heavy aid, 0 wide-layout aids, 1 packed-layout aids
     __device__ uint64_t operator()(int64_t x) const {
         const uint64_t n = cnt64[x] & CNT_REC_MASK;
         if (n == 0) return 0;
         if (only_flagged && !flag[x]) return 0;
         const int b = n <= (uint64_t)S_CAP ? 0 : (n <= (uint64_t)M_CAP ? 1 : 2);
         if (b != bin) return 0;
-        return bin == 2 ? (1ull << l_log2r(n, boost[x], l_cap)) : 1ull;
+        if (bin != 2) return 1ull;
+        if (mode >= 0 && (int)heavy_packed(cnt64[x], allow_packed) != mode) return 0;
+        return 1ull << l_log2r(cnt64[x], boost[x], l_cap, allow_packed);
     }
 };
 
@@ -891,17 +909,18 @@ struct ItemAny {     // 1 if aid x has work items in this bin
     __device__ uint64_t operator()(int64_t x) const { return f(x) ? 1ull : 0ull; }
 };
 
-// Processing order of the L bin: the first partition of every heavy aid ("pilot"), then all other partitions. The
-// pilots leave their top-k threshold in tau[x], which lets the aid's other partitions finish in one table pass.
-__global__ void k_fill_order(ItemCount f, uint32_t n_aids, const uint64_t* item_start, const uint64_t* aid_rank,
-                             uint64_t n_pilots, uint32_t* order) {
+// Processing order of one layout's heavy aids: the first partition of every aid ("pilot"), then all other
+// partitions. The pilots leave their top-k threshold in tau[x], which lets the aid's other partitions finish in one
+// table pass. f counts this layout's items; item_start (all heavy aids) gives the item index.
+__global__ void k_fill_order(ItemCount f, uint32_t n_aids, const uint64_t* item_start, const uint64_t* mode_start,
+                             const uint64_t* aid_rank, uint64_t n_pilots, uint32_t* order) {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n_aids) return;
     const uint64_t c = f((int64_t)x);
     if (!c) return;
-    const uint64_t s = item_start[x], r = aid_rank[x];
+    const uint64_t s = item_start[x], sm = mode_start[x], r = aid_rank[x];
     order[r] = (uint32_t)s;
-    for (uint64_t p = 1; p < c; ++p) order[n_pilots + s + p - r - 1] = (uint32_t)(s + p);
+    for (uint64_t p = 1; p < c; ++p) order[n_pilots + sm + p - r - 1] = (uint32_t)(s + p);
 }
 
 // item = x | part << 26 | log2R << 50
@@ -931,6 +950,8 @@ struct ReduceArgs {
     const uint64_t* items;
     const uint32_t* order;         // processing order (dequeue index -> item index), null = identity
     uint32_t n_items;
+    uint32_t n_work;               // entries of `order` (= n_items without an order)
+    int allow_packed;              // heavy aids with < 4096 runs use the packed layout (not in the time group)
     const uint64_t* cnt64;         // [n_aids] runs << 36 | records
     const uint64_t* run_start;     // [n_aids+1]
     const uint64_t* sorted_desc;
@@ -1117,6 +1138,7 @@ struct PartArgs {
     uint32_t* ptw;
     uint32_t l_cap;
     int window_max;                // largest window (records per run <= window_max - 1)
+    int allow_packed;
 };
 
 template <bool SCATTER>
@@ -1132,9 +1154,9 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
         const uint64_t ch = a.chunks[ci];
         const uint32_t x = (uint32_t)(ch & REC_AID_MASK);
         const uint64_t c = ch >> 26;
-        const int lgR = l_log2r(a.cnt64[x] & CNT_REC_MASK, a.boost[x], a.l_cap);
+        const int lgR = l_log2r(a.cnt64[x], a.boost[x], a.l_cap, a.allow_packed);
         const uint32_t R = 1u << lgR, pmask = R - 1u;
-        const int pshift = 32 - L_LOG2T - lgR;
+        const int pshift = 32 - heavy_log2t(a.cnt64[x], a.allow_packed) - lgR;
         const uint64_t g0 = a.litem_start[x];
         const uint64_t x_base = SCATTER ? a.pstart[g0] : 0ull;
         const uint64_t rb = a.run_start[x] + c * PART_CHUNK_RUNS;
@@ -1217,11 +1239,12 @@ struct ChunkCount {   // partition-pass work items of aid x: ceil(runs / PART_CH
     const uint32_t* flag;
     int only_flagged;
     uint32_t l_cap;
+    int allow_packed;
     __device__ uint64_t operator()(int64_t x) const {
         const uint64_t n = cnt64[x] & CNT_REC_MASK;
         if (n <= (uint64_t)M_CAP) return 0;
         if (only_flagged && !flag[x]) return 0;
-        if (l_log2r(n, boost[x], l_cap) == 0) return 0;
+        if (l_log2r(cnt64[x], boost[x], l_cap, allow_packed) == 0) return 0;
         return ((cnt64[x] >> CNT_REC_BITS) + PART_CHUNK_RUNS - 1) / PART_CHUNK_RUNS;
     }
 };
@@ -1287,12 +1310,16 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     // ---- item pipeline: (index, item word, run range, bucket range) of the NEXT item are fetched while the
     //      current one is reduced, so the dependent loads index -> item -> run_start are off the critical path
     auto fetch_item = [&](uint32_t idx, ItemDesc& d) {     // stage 1: item word
-        d.it = (a.order && idx < a.n_items) ? a.order[idx] : idx;
-        d.item = idx < a.n_items ? a.items[d.it] : 0ull;
+        d.it = 0xFFFFFFFFu;             // past the end of the work list
+        d.item = 0ull;
+        if (idx < a.n_work) {
+            d.it = a.order ? a.order[idx] : idx;
+            d.item = a.items[d.it];
+        }
     };
     auto fetch_ranges = [&](ItemDesc& d) {                 // stage 2: ranges (needs the item word)
         d.rb = d.re = d.ps = d.pe = 0;
-        if (d.it < a.n_items) {
+        if (d.it != 0xFFFFFFFFu) {
             const uint32_t xx = (uint32_t)(d.item & REC_AID_MASK);
             d.rb = a.run_start[xx];
             d.re = a.run_start[xx + 1];
@@ -1336,7 +1363,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             __syncthreads();
             cur = s_cur;
         }
-        if (cur.it >= a.n_items) break;
+        if (cur.it == 0xFFFFFFFFu) break;
         OTTO_PH(0);
         const uint32_t it = cur.it;
         // stage 1 of the next item
@@ -1398,14 +1425,12 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 const unsigned long long add = (unsigned long long)add0 | ((unsigned long long)add1 << 12) |
                                                ((unsigned long long)add2 << 24);
                 const unsigned long long fresh = (unsigned long long)y << 36;
+                // CAS first, no read: a new key (most records of these bins) costs ONE LDS operation -- it goes in
+                // together with its first count; a key already there costs the failed CAS + one add
                 for (int probe = 0; probe < T; ++probe) {
-                    const uint64_t v = s_tab[slot];
-                    bool mine = v != TAB_EMPTY && (uint32_t)(v >> 36) == y;
-                    if (v == TAB_EMPTY) {
-                        const unsigned long long old = atomicCAS((unsigned long long*)&s_tab[slot], (unsigned long long)TAB_EMPTY, fresh);
-                        mine = old == TAB_EMPTY || (uint32_t)(old >> 36) == y;
-                    }
-                    if (mine) {
+                    const unsigned long long old = atomicCAS((unsigned long long*)&s_tab[slot], (unsigned long long)TAB_EMPTY, fresh | add);
+                    if (old == TAB_EMPTY) return;
+                    if ((uint32_t)(old >> 36) == y) {
                         atomicAdd((unsigned long long*)&s_tab[slot], add);
                         return;
                     }
@@ -1415,13 +1440,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 return;
             }
             int found = -1;
-            for (int probe = 0; probe < T; ++probe) {
-                const uint32_t kx = s_key[slot];
-                if (kx == y) { found = (int)slot; break; }
-                if (kx == KEY_EMPTY) {
-                    const uint32_t old = atomicCAS(&s_key[slot], KEY_EMPTY, y);
-                    if (old == KEY_EMPTY || old == y) { found = (int)slot; break; }
-                }
+            for (int probe = 0; probe < T; ++probe) {            // CAS first, no read (see the packed layout)
+                const uint32_t old = atomicCAS(&s_key[slot], KEY_EMPTY, y);
+                if (old == KEY_EMPTY || old == y) { found = (int)slot; break; }
                 slot = (slot + 1) & (T - 1);
             }
             if (found < 0) { s_ovf = 1; return; }
@@ -1478,7 +1499,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         } else if (lgR > 0 && a.pstart) {
             // heavy aid, records already bucketed by hash partition: contiguous coalesced reads
             const uint64_t ps = cur.ps, pe = cur.pe;
-            constexpr int BU = GROUP == OTTO_COVIS_GROUP_TIME ? 4 : 6;     // l_cap = 6 * 1024: one round trip per partition
+            // records per thread and round trip: a whole partition (wide: l_cap = 6 * 1024, packed: 12 * 1024) in one
+            constexpr int BU = GROUP == OTTO_COVIS_GROUP_TIME ? 4 : ((PACKED && THREADS == L_THREADS) ? 12 : 6);
             for (uint64_t i0 = ps + threadIdx.x; i0 < pe; i0 += BU * THREADS) {
                 uint32_t rc[BU], e[BU];
 #pragma unroll
@@ -1560,7 +1582,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             // LDS table full: ask the host to redo this aid with twice the partitions
             if (threadIdx.x == 0) {
                 a.flag[x] = 1;
-                a.boost[x] = (uint8_t)(lgR - l_log2r(a.cnt64[x] & CNT_REC_MASK, 0, a.l_cap) + 1);
+                a.boost[x] = (uint8_t)(lgR - l_log2r(a.cnt64[x], 0, a.l_cap, a.allow_packed) + 1);
                 atomicAdd(a.ovf_count, 1u);
             }
         } else {
@@ -1971,7 +1993,10 @@ struct otto_covis_ctx {
     DevBuf part_y, part_w;
     DevBuf bcount, bstart, tmp_runs;          // bucketed index
     int bucket_index = 1;          // option "bucket_index": LDS-atomic index build (0 = global-atomic histogram)
-    DevBuf lorder, lrank;          // L bin: pilot-first processing order
+    DevBuf lorder[2], lrank, lmode_start;   // L bin: pilot-first processing order per layout (0 wide, 1 packed)
+    uint64_t n_order[2] = {0, 0};
+    int packed_heavy = 1;          // option "packed_heavy": packed layout for heavy aids with < 4096 runs
+    int items_allow_packed = -1;   // layout rule the L item list was built with (-1: not built)
     DevBuf tau_w, tau_y;           // threshold guesses of partitioned heavy aids (per reduce pass)
     int guess = 1;                 // option "guess": single-pass top-k from a sibling partition's threshold
     DevBuf exp_run_pos, exp_rec_pos, exp_totals;
@@ -2022,7 +2047,7 @@ extern "C" void otto_covis_destroy(otto_covis_ctx* c) {
                      &c->cls_pos[0], &c->cls_pos[1], &c->cls_pos[2], &c->cls_pos[3], &c->cls_pos[4], &c->cls_pos[5],
                      &c->sess_list, &c->cls_byte,
                      &c->run_start, &c->run_rank, &c->sorted_desc, &c->item_start, &c->boost, &c->flag, &c->counters,
-                     &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->tau_w, &c->tau_y, &c->lorder, &c->lrank, &c->bcount, &c->bstart, &c->tmp_runs, &c->exp_run_pos, &c->exp_rec_pos, &c->exp_totals,
+                     &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->tau_w, &c->tau_y, &c->lorder[0], &c->lorder[1], &c->lrank, &c->lmode_start, &c->bcount, &c->bstart, &c->tmp_runs, &c->exp_run_pos, &c->exp_rec_pos, &c->exp_totals,
                      &c->litem_start, &c->chunks, &c->pcount, &c->pcursor, &c->pstart, &c->prec, &c->ptw};
     for (DevBuf* b : all) b->release();
     if (c->ev_ok)
@@ -2180,9 +2205,10 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
     return 0;
 }
 
-static int build_items(otto_covis_ctx* c, int bin, int only_flagged, hipStream_t s) {
+static int build_items(otto_covis_ctx* c, int bin, int only_flagged, hipStream_t s, int allow_packed = 0) {
     const uint32_t n_aids = c->p.n_aids;
-    ItemCount f{c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(), c->flag.as<uint32_t>(), bin, only_flagged, c->l_cap};
+    ItemCount f{c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(), c->flag.as<uint32_t>(), bin, only_flagged, c->l_cap, allow_packed, -1};
+    if (bin == 2) c->items_allow_packed = allow_packed;
     OTTO_TRY(device_scan(f, (int64_t)n_aids, c->item_start.as<uint64_t>(), c->partial.as<uint64_t>(), s));
     uint64_t total = 0;
     OTTO_HIP(hipMemcpyAsync(&total, c->item_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
@@ -2194,22 +2220,33 @@ static int build_items(otto_covis_ctx* c, int bin, int only_flagged, hipStream_t
         k_fill_items<<<(n_aids + 255) / 256, 256, 0, s>>>(f, n_aids, c->item_start.as<uint64_t>(), c->items[bin].as<uint64_t>());
         OTTO_HIP(hipGetLastError());
     }
-    if (bin == 2 && total) {
-        OTTO_TRY(c->lrank.ensure((size_t)(n_aids + 1) * 8, 0, s));
-        OTTO_TRY(device_scan(ItemAny{f}, (int64_t)n_aids, c->lrank.as<uint64_t>(), c->partial.as<uint64_t>(), s));
-        uint64_t n_pilots = 0;
-        OTTO_HIP(hipMemcpyAsync(&n_pilots, c->lrank.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
-        OTTO_HIP(hipStreamSynchronize(s));
-        OTTO_TRY(c->lorder.ensure((size_t)total * 4, 0, s));
-        k_fill_order<<<(n_aids + 255) / 256, 256, 0, s>>>(f, n_aids, c->item_start.as<uint64_t>(), c->lrank.as<uint64_t>(), n_pilots,
-                                                          c->lorder.as<uint32_t>());
-        OTTO_HIP(hipGetLastError());
+    if (bin == 2) {
+        // processing order per table layout (pilots first); item_start still holds the item index of every heavy aid
+        c->n_order[0] = c->n_order[1] = 0;
+        for (int mode = 0; mode < 2 && total; ++mode) {
+            ItemCount fm = f;
+            fm.mode = mode;
+            OTTO_TRY(c->lrank.ensure((size_t)(n_aids + 1) * 8, 0, s));
+            OTTO_TRY(c->lmode_start.ensure((size_t)(n_aids + 1) * 8, 0, s));
+            OTTO_TRY(device_scan(ItemAny{fm}, (int64_t)n_aids, c->lrank.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+            OTTO_TRY(device_scan(fm, (int64_t)n_aids, c->lmode_start.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+            uint64_t n_pilots = 0, n_mode = 0;
+            OTTO_HIP(hipMemcpyAsync(&n_pilots, c->lrank.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
+            OTTO_HIP(hipMemcpyAsync(&n_mode, c->lmode_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
+            OTTO_HIP(hipStreamSynchronize(s));
+            c->n_order[mode] = n_mode;
+            if (!n_mode) continue;
+            OTTO_TRY(c->lorder[mode].ensure((size_t)n_mode * 4, 0, s));
+            k_fill_order<<<(n_aids + 255) / 256, 256, 0, s>>>(fm, n_aids, c->item_start.as<uint64_t>(), c->lmode_start.as<uint64_t>(),
+                                                              c->lrank.as<uint64_t>(), n_pilots, c->lorder[mode].as<uint32_t>());
+            OTTO_HIP(hipGetLastError());
+        }
     }
     if (bin == 2) {
         // heavy aids: first L item of every aid + the work items of the partition pass
         OTTO_TRY(c->litem_start.ensure((size_t)(n_aids + 1) * 8, 0, s));
         OTTO_HIP(hipMemcpyAsync(c->litem_start.p, c->item_start.p, (size_t)(n_aids + 1) * 8, hipMemcpyDeviceToDevice, s));
-        ChunkCount cf{c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(), c->flag.as<uint32_t>(), only_flagged, c->l_cap};
+        ChunkCount cf{c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(), c->flag.as<uint32_t>(), only_flagged, c->l_cap, allow_packed};
         OTTO_TRY(device_scan(cf, (int64_t)n_aids, c->item_start.as<uint64_t>(), c->partial.as<uint64_t>(), s));
         uint64_t nch = 0;
         OTTO_HIP(hipMemcpyAsync(&nch, c->item_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
@@ -2307,7 +2344,7 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
         OTTO_TRY(device_scan(BinRuns{c->cnt64.as<uint64_t>(), bin}, (int64_t)n_aids, c->item_start.as<uint64_t>(),
                              c->partial.as<uint64_t>(), s));
         OTTO_HIP(hipMemcpyAsync(&c->bin_runs[bin], c->item_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
-        OTTO_TRY(build_items(c, bin, 0, s));
+        OTTO_TRY(build_items(c, bin, 0, s, c->packed_heavy));
     }
     tend(c, OTTO_COVIS_T_INDEX, s);
     c->retries = 0;
@@ -2319,8 +2356,10 @@ template <int GROUP>
 static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s) {
     a.items = c->items[bin].as<uint64_t>();
     a.n_items = (uint32_t)c->n_items[bin];
+    a.n_work = a.n_items;
     if (a.n_items == 0) return 0;
-    a.order = (bin == 2 && c->guess && c->partition) ? c->lorder.as<uint32_t>() : nullptr;
+    a.order = nullptr;
+    a.allow_packed = c->items_allow_packed > 0;
     uint32_t* wc = c->counters.as<uint32_t>() + 1 + bin;
     OTTO_HIP(hipMemsetAsync(wc, 0, 4, s));
     a.work_counter = wc;
@@ -2363,7 +2402,8 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
             PartArgs pa{c->chunks.as<uint64_t>(), (uint32_t)c->n_chunks, c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(),
                         c->run_start.as<uint64_t>(), c->sorted_desc.as<uint64_t>(), c->rec.as<uint32_t>(), c->tw.as<uint32_t>(),
                         c->litem_start.as<uint64_t>(), c->pcount.as<uint32_t>(), c->pcursor.as<uint32_t>(),
-                        c->pstart.as<uint64_t>(), c->prec.as<uint32_t>(), time ? c->ptw.as<uint32_t>() : nullptr, c->l_cap, c->p.window};
+                        c->pstart.as<uint64_t>(), c->prec.as<uint32_t>(), time ? c->ptw.as<uint32_t>() : nullptr, c->l_cap, c->p.window,
+                        a.allow_packed};
             const uint32_t pgrid = (uint32_t)(c->n_chunks < 256u * 5u ? c->n_chunks : 256u * 5u);
             const uint32_t cgrid = (uint32_t)(c->n_chunks < 256u * 8u ? c->n_chunks : 256u * 8u);
             k_partition<false><<<cgrid, 256, 0, s>>>(pa);
@@ -2376,9 +2416,23 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
             a.prec = c->prec.as<uint32_t>();
             a.ptw = c->ptw.as<uint32_t>();
         }
-        uint32_t grid = a.n_items < 256u ? a.n_items : 256u;
         tbegin(c, OTTO_COVIS_T_REDUCE_L, s);
-        k_reduce<L_LOG2T, L_THREADS, GROUP, false, 4, 2><<<grid, L_THREADS, 0, s>>>(a);
+        // the two table layouts of heavy aids: each kernel walks its own pilot-first order over the shared item list
+        for (int mode = 1; mode >= 0; --mode) {
+            if (!c->n_order[mode]) continue;
+            ReduceArgs am = a;
+            am.order = c->lorder[mode].as<uint32_t>();
+            am.n_work = (uint32_t)c->n_order[mode];
+            OTTO_HIP(hipMemsetAsync(wc, 0, 4, s));
+            const uint32_t grid = am.n_work < 256u ? am.n_work : 256u;
+            if (mode == 1) {
+                if constexpr (GROUP != OTTO_COVIS_GROUP_TIME)
+                    k_reduce<LP_LOG2T, L_THREADS, GROUP, true, 4, 2><<<grid, L_THREADS, 0, s>>>(am);
+            } else {
+                k_reduce<L_LOG2T, L_THREADS, GROUP, false, 4, 2><<<grid, L_THREADS, 0, s>>>(am);
+            }
+            OTTO_HIP(hipGetLastError());
+        }
         tend(c, OTTO_COVIS_T_REDUCE_L, s);
         OTTO_HIP(hipGetLastError());
         tbegin(c, OTTO_COVIS_T_MERGE, s);
@@ -2415,6 +2469,9 @@ extern "C" int otto_covis_finalize(otto_covis_ctx* c, int group, int k, uint32_t
     OTTO_REQUIRE(n_kinds > 0, "group %d has no kinds configured", group);
     hipStream_t s = (hipStream_t)stream;
     if (!c->index_valid) OTTO_TRY(build_index(c, s));
+    // the time group has no packed layout: its heavy aids are partitioned for the wide table
+    const int want_packed = (group != OTTO_COVIS_GROUP_TIME && c->packed_heavy) ? 1 : 0;
+    if (c->items_allow_packed != want_packed) OTTO_TRY(build_items(c, 2, 0, s, want_packed));
     const uint32_t n_aids = p.n_aids;
     OTTO_HIP(hipMemsetAsync(d_out_n, 0, (size_t)n_kinds * n_aids * 4, s));
 
@@ -2476,11 +2533,11 @@ extern "C" int otto_covis_finalize(otto_covis_ctx* c, int group, int k, uint32_t
             // some heavy aids overflowed their LDS table: re-partition only those (boost[x] was raised)
             c->retries++;
             OTTO_REQUIRE(c->retries < 64, "overflow re-partitioning did not converge");
-            OTTO_TRY(build_items(c, 2, 1, s));
+            OTTO_TRY(build_items(c, 2, 1, s, c->items_allow_packed));
             OTTO_HIP(hipMemsetAsync(c->flag.p, 0, (size_t)n_aids * 4, s));
             first = false;
         }
-        if (!first) OTTO_TRY(build_items(c, 2, 0, s));   // restore the full L list (boost kept) for later passes
+        if (!first) OTTO_TRY(build_items(c, 2, 0, s, c->items_allow_packed));   // restore the full L list (boost kept) for later passes
     }
     return 0;
 }
@@ -2496,6 +2553,7 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
         return 0;
     }
     if (strcmp(name, "debug_skip") == 0) { c->debug_skip = (int)value; return 0; }   // timing diagnostics, results invalid
+    if (strcmp(name, "packed_heavy") == 0) { c->packed_heavy = value != 0; c->index_valid = false; return 0; }
     if (strcmp(name, "bucket_index") == 0) { c->bucket_index = value != 0; return 0; }
     if (strcmp(name, "guess") == 0) { c->guess = value != 0; return 0; }           // threshold guessing on/off (A/B)
     if (strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }           // fused in-order expansion on/off (A/B)
