@@ -1623,6 +1623,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             // ops), with a per-kind bitmask of the slots of this lane that are already in a list.
             K lb[PKD];
             uint32_t done[PKD];
+            uint32_t nonempty = 0;                   // slots of this lane that hold a key (the later passes skip the rest)
             {
                 int bi[PKD];
 #pragma unroll
@@ -1631,9 +1632,13 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 for (int q = 0; q < MPL; ++q) {      // NOT fully unrolled: keeps a couple of slots in flight, not all MPL
                     K kk[PKD];
                     slot_keys(q * THREADS + threadIdx.x, kk);
+                    bool any = false;
 #pragma unroll
-                    for (int j = 0; j < PKD; ++j)
+                    for (int j = 0; j < PKD; ++j) {
+                        any = any || kvalid(kk[j]);
                         if (kbetter(kk[j], lb[j])) { lb[j] = kk[j]; bi[j] = q; }
+                    }
+                    if (any) nonempty |= 1u << q;
                 }
 #pragma unroll
                 for (int j = 0; j < PKD; ++j) done[j] = 1u << bi[j];
@@ -1712,19 +1717,24 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                     K thr[PKD];
 #pragma unroll
                     for (int j = 0; j < PKD; ++j) kload(thr[j], s_thrw[j], s_thry[j]);
-#pragma unroll 2
-                    for (int q = 0; q < MPL; ++q) {
-                        K kk[PKD];
-                        slot_keys(q * THREADS + threadIdx.x, kk);
+                    // only the non-empty slots: the wave runs as many rounds as its fullest lane has keys
+                    uint32_t rem = nonempty;
+                    while (__ballot(rem != 0) != 0) {
+                        if (rem != 0) {
+                            const int q = __builtin_ctz(rem);
+                            rem &= rem - 1u;
+                            K kk[PKD];
+                            slot_keys(q * THREADS + threadIdx.x, kk);
 #pragma unroll
-                        for (int j = 0; j < PKD; ++j) {
-                            if (j < a.nk && !((done[j] >> q) & 1u) && kvalid(kk[j]) && kbetter(kk[j], thr[j])) {
-                                const uint32_t pos = atomicAdd(&s_nex[j], 1u);
-                                if (pos < (uint32_t)EXCAP) {
-                                    kstore(kk[j], &s_exw[j][pos], &s_exy[0][WIDE ? pos : 0]);
-                                    done[j] |= 1u << q;
-                                } else {
-                                    s_more = 1;
+                            for (int j = 0; j < PKD; ++j) {
+                                if (j < a.nk && !((done[j] >> q) & 1u) && kvalid(kk[j]) && kbetter(kk[j], thr[j])) {
+                                    const uint32_t pos = atomicAdd(&s_nex[j], 1u);
+                                    if (pos < (uint32_t)EXCAP) {
+                                        kstore(kk[j], &s_exw[j][pos], &s_exy[0][WIDE ? pos : 0]);
+                                        done[j] |= 1u << q;
+                                    } else {
+                                        s_more = 1;
+                                    }
                                 }
                             }
                         }
