@@ -6,7 +6,7 @@ scaled by a calibration launch of KNOWN size with the same 4-byte-per-lane acces
 import collections, csv, glob, json, sys
 
 def load(d):
-    f = glob.glob(d + '/*/*_counter_collection.csv')[0]
+    f = (glob.glob(d + '/*_counter_collection.csv') + glob.glob(d + '/*/*_counter_collection.csv'))[0]
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         per[r['Kernel_Name']].append(float(r['Counter_Value']))
