@@ -846,20 +846,26 @@ constexpr int L_LOG2T = 13, L_THREADS = 1024, L_CAP = 6144;
 // twice the records, half the work items. The others, and the time group, keep the wide layout (2^13 slots).
 constexpr int LP_LOG2T = 14;
 constexpr uint64_t PACKED_MAX_RUNS = 4096;
-__device__ __forceinline__ bool heavy_packed(uint64_t c64, int allow_packed) {
-    return allow_packed && (c64 >> CNT_REC_BITS) < PACKED_MAX_RUNS;
+// Layouts ("modes") of the heavy bin:  0: wide, 2^13 slots, partitions of l_cap records;
+//   1: packed, 2^14 slots, partitions of 2 * l_cap;  2: packed, 2^13 slots, the whole aid (n <= l_cap), 8 waves, two
+//   workgroups per CU. (Smaller tables for the small aids of the M bin were measured and did not pay.)
+__device__ __forceinline__ int heavy_mode(uint64_t c64, int allow_packed, uint32_t l_cap) {
+    if (!allow_packed || (c64 >> CNT_REC_BITS) >= PACKED_MAX_RUNS) return 0;
+    return (c64 & CNT_REC_MASK) <= (uint64_t)l_cap ? 2 : 1;
 }
-__device__ __forceinline__ int heavy_log2t(uint64_t c64, int allow_packed) { return heavy_packed(c64, allow_packed) ? LP_LOG2T : L_LOG2T; }
+__device__ __forceinline__ int heavy_log2t(uint64_t c64, int allow_packed, uint32_t l_cap) {
+    return heavy_mode(c64, allow_packed, l_cap) == 1 ? LP_LOG2T : L_LOG2T;
+}
 
 // log2 of the number of hash partitions of a heavy aid (records n, layout from its run count)
 __device__ __forceinline__ int l_log2r(uint64_t c64, int boost, uint32_t l_cap, int allow_packed) {
     const uint64_t n = c64 & CNT_REC_MASK;
-    const uint64_t cap = heavy_packed(c64, allow_packed) ? 2ull * l_cap : (uint64_t)l_cap;
+    const uint64_t cap = heavy_mode(c64, allow_packed, l_cap) == 1 ? 2ull * l_cap : (uint64_t)l_cap;
     uint64_t parts = (n + cap - 1) / cap;
     int lg = 0;
     while ((1ull << lg) < parts) ++lg;
     lg += boost;
-    const int maxlg = 32 - heavy_log2t(c64, allow_packed);
+    const int maxlg = 32 - heavy_log2t(c64, allow_packed, l_cap);
     return lg > maxlg ? maxlg : lg;
 }
 
@@ -871,15 +877,16 @@ struct ItemCount {   // number of work items aid x contributes to bin `bin`
     int only_flagged;
     uint32_t l_cap;
     int allow_packed;
-    int mode;                      // bin 2 only: -1 every heavy aid, 0 wide-layout aids, 1 packed-layout aids
+    int mode;                      // bins 1 and 2: -1 every aid of the bin, else only the aids of this tier / layout
     __device__ uint64_t operator()(int64_t x) const {
         const uint64_t n = cnt64[x] & CNT_REC_MASK;
         if (n == 0) return 0;
         if (only_flagged && !flag[x]) return 0;
         const int b = n <= (uint64_t)S_CAP ? 0 : (n <= (uint64_t)M_CAP ? 1 : 2);
         if (b != bin) return 0;
-        if (bin != 2) return 1ull;
-        if (mode >= 0 && (int)heavy_packed(cnt64[x], allow_packed) != mode) return 0;
+        if (bin == 0) return 1ull;
+        if (bin == 1) return 1ull;
+        if (mode >= 0 && heavy_mode(cnt64[x], allow_packed, l_cap) != mode) return 0;
         return 1ull << l_log2r(cnt64[x], boost[x], l_cap, allow_packed);
     }
 };
@@ -1156,7 +1163,7 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
         const uint64_t c = ch >> 26;
         const int lgR = l_log2r(a.cnt64[x], a.boost[x], a.l_cap, a.allow_packed);
         const uint32_t R = 1u << lgR, pmask = R - 1u;
-        const int pshift = 32 - heavy_log2t(a.cnt64[x], a.allow_packed) - lgR;
+        const int pshift = 32 - heavy_log2t(a.cnt64[x], a.allow_packed, a.l_cap) - lgR;
         const uint64_t g0 = a.litem_start[x];
         const uint64_t x_base = SCATTER ? a.pstart[g0] : 0ull;
         const uint64_t rb = a.run_start[x] + c * PART_CHUNK_RUNS;
@@ -1357,6 +1364,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         fetch_item(blockIdx.x, cur);
         fetch_ranges(cur);
     }
+    uint32_t sidx = blockIdx.x;          // static schedule: position in the work list
 
     for (;;) {
         if (DYNAMIC) {
@@ -1370,7 +1378,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         if (DYNAMIC) {
             if (threadIdx.x == 0) fetch_item(idx_next, nx);
         } else {
-            fetch_item(it + gridDim.x, nx);
+            fetch_item(sidx + gridDim.x, nx);
         }
         const uint64_t item = cur.item;
         const uint32_t x = (uint32_t)(item & REC_AID_MASK);
@@ -1780,6 +1788,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             }
         } else {
             cur = nx;
+            sidx += gridDim.x;
         }
     }
 #ifdef OTTO_PHASE_PROF
@@ -2003,8 +2012,8 @@ struct otto_covis_ctx {
     DevBuf part_y, part_w;
     DevBuf bcount, bstart, tmp_runs;          // bucketed index
     int bucket_index = 1;          // option "bucket_index": LDS-atomic index build (0 = global-atomic histogram)
-    DevBuf lorder[2], lrank, lmode_start;   // L bin: pilot-first processing order per layout (0 wide, 1 packed)
-    uint64_t n_order[2] = {0, 0};
+    DevBuf lorder[3][3], lrank, lmode_start;   // [bin][mode] processing order of the tiers / layouts (heavy: pilots first)
+    uint64_t n_order[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     int packed_heavy = 1;          // option "packed_heavy": packed layout for heavy aids with < 4096 runs
     int items_allow_packed = -1;   // layout rule the L item list was built with (-1: not built)
     DevBuf tau_w, tau_y;           // threshold guesses of partitioned heavy aids (per reduce pass)
@@ -2057,7 +2066,7 @@ extern "C" void otto_covis_destroy(otto_covis_ctx* c) {
                      &c->cls_pos[0], &c->cls_pos[1], &c->cls_pos[2], &c->cls_pos[3], &c->cls_pos[4], &c->cls_pos[5],
                      &c->sess_list, &c->cls_byte,
                      &c->run_start, &c->run_rank, &c->sorted_desc, &c->item_start, &c->boost, &c->flag, &c->counters,
-                     &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->tau_w, &c->tau_y, &c->lorder[0], &c->lorder[1], &c->lrank, &c->lmode_start, &c->bcount, &c->bstart, &c->tmp_runs, &c->exp_run_pos, &c->exp_rec_pos, &c->exp_totals,
+                     &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->tau_w, &c->tau_y, &c->lorder[1][0], &c->lorder[1][1], &c->lorder[1][2], &c->lorder[2][0], &c->lorder[2][1], &c->lorder[2][2], &c->lrank, &c->lmode_start, &c->bcount, &c->bstart, &c->tmp_runs, &c->exp_run_pos, &c->exp_rec_pos, &c->exp_totals,
                      &c->litem_start, &c->chunks, &c->pcount, &c->pcursor, &c->pstart, &c->prec, &c->ptw};
     for (DevBuf* b : all) b->release();
     if (c->ev_ok)
@@ -2231,9 +2240,10 @@ static int build_items(otto_covis_ctx* c, int bin, int only_flagged, hipStream_t
         OTTO_HIP(hipGetLastError());
     }
     if (bin == 2) {
-        // processing order per table layout (pilots first); item_start still holds the item index of every heavy aid
-        c->n_order[0] = c->n_order[1] = 0;
-        for (int mode = 0; mode < 2 && total; ++mode) {
+        // processing order per table layout (pilots first); item_start holds the item index of every heavy aid
+        for (int mode = 0; mode < 3; ++mode) {
+            c->n_order[bin][mode] = 0;
+            if (!total) continue;
             ItemCount fm = f;
             fm.mode = mode;
             OTTO_TRY(c->lrank.ensure((size_t)(n_aids + 1) * 8, 0, s));
@@ -2244,11 +2254,11 @@ static int build_items(otto_covis_ctx* c, int bin, int only_flagged, hipStream_t
             OTTO_HIP(hipMemcpyAsync(&n_pilots, c->lrank.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
             OTTO_HIP(hipMemcpyAsync(&n_mode, c->lmode_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
             OTTO_HIP(hipStreamSynchronize(s));
-            c->n_order[mode] = n_mode;
+            c->n_order[bin][mode] = n_mode;
             if (!n_mode) continue;
-            OTTO_TRY(c->lorder[mode].ensure((size_t)n_mode * 4, 0, s));
+            OTTO_TRY(c->lorder[bin][mode].ensure((size_t)n_mode * 4, 0, s));
             k_fill_order<<<(n_aids + 255) / 256, 256, 0, s>>>(fm, n_aids, c->item_start.as<uint64_t>(), c->lmode_start.as<uint64_t>(),
-                                                              c->lrank.as<uint64_t>(), n_pilots, c->lorder[mode].as<uint32_t>());
+                                                              c->lrank.as<uint64_t>(), n_pilots, c->lorder[bin][mode].as<uint32_t>());
             OTTO_HIP(hipGetLastError());
         }
     }
@@ -2428,17 +2438,24 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
         }
         tbegin(c, OTTO_COVIS_T_REDUCE_L, s);
         // the two table layouts of heavy aids: each kernel walks its own pilot-first order over the shared item list
-        for (int mode = 1; mode >= 0; --mode) {
-            if (!c->n_order[mode]) continue;
+        for (int mode = 2; mode >= 0; --mode) {
+            if (!c->n_order[2][mode]) continue;
             ReduceArgs am = a;
-            am.order = c->lorder[mode].as<uint32_t>();
-            am.n_work = (uint32_t)c->n_order[mode];
+            am.order = c->lorder[2][mode].as<uint32_t>();
+            am.n_work = (uint32_t)c->n_order[2][mode];
             OTTO_HIP(hipMemsetAsync(wc, 0, 4, s));
-            const uint32_t grid = am.n_work < 256u ? am.n_work : 256u;
-            if (mode == 1) {
-                if constexpr (GROUP != OTTO_COVIS_GROUP_TIME)
+            if (mode == 2) {
+                if constexpr (GROUP != OTTO_COVIS_GROUP_TIME) {
+                    const uint32_t grid = am.n_work < 256u * 2u ? am.n_work : 256u * 2u;
+                    k_reduce<L_LOG2T, 512, GROUP, true, 4, 4><<<grid, 512, 0, s>>>(am);
+                }
+            } else if (mode == 1) {
+                if constexpr (GROUP != OTTO_COVIS_GROUP_TIME) {
+                    const uint32_t grid = am.n_work < 256u ? am.n_work : 256u;
                     k_reduce<LP_LOG2T, L_THREADS, GROUP, true, 4, 2><<<grid, L_THREADS, 0, s>>>(am);
+                }
             } else {
+                const uint32_t grid = am.n_work < 256u ? am.n_work : 256u;
                 k_reduce<L_LOG2T, L_THREADS, GROUP, false, 4, 2><<<grid, L_THREADS, 0, s>>>(am);
             }
             OTTO_HIP(hipGetLastError());
