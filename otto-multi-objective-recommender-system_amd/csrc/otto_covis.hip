@@ -1899,30 +1899,53 @@ __device__ __forceinline__ int owner_of(const OwnerArgs& a, uint32_t x) {
     return o;
 }
 
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_export_all(OwnerArgs a) {
-    __shared__ unsigned long long s_rr[MAX_OWNERS];      // runs << 32 | records of this block per owner: ONE atomic hands a
-                                                         // run its rank AND its record offset, so both orders agree
+// plan: runs and records per owner. A streaming reduction: LDS accumulators live across the block's whole grid-stride
+// loop, one global atomic per owner and block at the end.
+__global__ __launch_bounds__(256) void k_export_plan(OwnerArgs a) {
+    __shared__ unsigned long long s_tot[MAX_OWNERS];
+    if (threadIdx.x < MAX_OWNERS) s_tot[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_slots; i += (int64_t)gridDim.x * 256) {
+        const uint64_t d = a.run_desc[i];
+        const uint32_t len = (uint32_t)(d & 0xFFull);
+        if (len) atomicAdd(&s_tot[owner_of(a, a.run_x[i])], (1ull << CNT_REC_BITS) | len);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.n_owners && s_tot[threadIdx.x]) atomicAdd(&a.totals[threadIdx.x], s_tot[threadIdx.x]);
+}
+
+// fill: chunks of EXP_CHUNK run slots per workgroup round. Block-local LDS ranks (one packed word hands a run its rank
+// AND its record offset, so both orders agree), one global cursor bump per chunk and owner, headers written by the
+// run's thread, records copied by one 32-lane half-wave per run (contiguous reads and writes).
+constexpr int EXP_CHUNK = 512;
+__global__ __launch_bounds__(256) void k_export_fill(OwnerArgs a) {
+    constexpr int PER = EXP_CHUNK / 256;
+    __shared__ unsigned long long s_rr[MAX_OWNERS];      // runs << 32 | records of this chunk per owner
     __shared__ unsigned long long s_rbase[MAX_OWNERS], s_cbase[MAX_OWNERS];
-    __shared__ uint64_t s_src[256], s_dst[256];
-    __shared__ uint32_t s_len[256];
-    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < a.n_slots; b0 += (int64_t)gridDim.x * 256) {
+    __shared__ uint64_t s_src[EXP_CHUNK], s_dst[EXP_CHUNK];
+    __shared__ uint8_t s_len[EXP_CHUNK];
+    const int64_t n_chunks = (a.n_slots + EXP_CHUNK - 1) / EXP_CHUNK;
+    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
         if (threadIdx.x < MAX_OWNERS) s_rr[threadIdx.x] = 0;
         __syncthreads();
-        const int64_t i = b0 + threadIdx.x;
-        uint64_t d = 0;
-        uint32_t x = 0, len = 0;
-        int o = 0;
-        uint32_t my_run = 0, my_rec = 0;
-        if (i < a.n_slots) {
-            d = a.run_desc[i];
-            len = (uint32_t)(d & 0xFFull);
+        uint64_t d[PER];
+        uint32_t x[PER], my_run[PER], my_rec[PER];
+        int o[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int64_t i = ch * EXP_CHUNK + (int64_t)u * 256 + threadIdx.x;
+            d[u] = i < a.n_slots ? a.run_desc[i] : 0ull;
+            x[u] = 0; o[u] = 0; my_run[u] = my_rec[u] = 0;
+            if (d[u] & 0xFFull) x[u] = a.run_x[i];
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const uint32_t len = (uint32_t)(d[u] & 0xFFull);
             if (len) {
-                x = a.run_x[i];
-                o = owner_of(a, x);
-                const unsigned long long old = atomicAdd(&s_rr[o], (1ull << 32) | len);
-                my_run = (uint32_t)(old >> 32);               // rank of this run / offset of its records in the block's share
-                my_rec = (uint32_t)old;
+                o[u] = owner_of(a, x[u]);
+                const unsigned long long old = atomicAdd(&s_rr[o[u]], (1ull << 32) | len);
+                my_run[u] = (uint32_t)(old >> 32);
+                my_rec[u] = (uint32_t)old;
             }
         }
         __syncthreads();
@@ -1937,26 +1960,37 @@ __global__ __launch_bounds__(256) void k_export_all(OwnerArgs a) {
             s_rbase[threadIdx.x] = rb;
             s_cbase[threadIdx.x] = cb;
         }
-        if (FILL) {
-            __syncthreads();
-            s_len[threadIdx.x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int r = u * 256 + threadIdx.x;
+            const uint32_t len = (uint32_t)(d[u] & 0xFFull);
+            s_len[r] = (uint8_t)len;
             if (len) {
-                const uint64_t rp = a.run_base[o] + s_rbase[o] + my_run;
-                const uint64_t cp = a.rec_base[o] + s_cbase[o] + my_rec;
-                a.o_hdr[2 * rp] = x;
-                a.o_hdr[2 * rp + 1] = len;
-                s_src[threadIdx.x] = d >> 8;
-                s_dst[threadIdx.x] = cp;
-                s_len[threadIdx.x] = len;
+                const uint64_t rp = a.run_base[o[u]] + s_rbase[o[u]] + my_run[u];
+                const uint64_t cp = a.rec_base[o[u]] + s_cbase[o[u]] + my_rec[u];
+                *reinterpret_cast<uint2*>(&a.o_hdr[2 * rp]) = make_uint2(x[u], len);
+                s_src[r] = d[u] >> 8;
+                s_dst[r] = cp;
             }
-            __syncthreads();
-            // copy the records: one 32-lane half-wave per run -> contiguous reads and writes
-            const int hw = threadIdx.x >> 5, l = threadIdx.x & 31;
-            for (int r = hw; r < 256; r += 8) {
-                const uint32_t ln = s_len[r];
-                if ((uint32_t)l < ln) {
-                    a.o_rec[s_dst[r] + l] = a.rec[s_src[r] + l];
-                    if (a.o_tw) a.o_tw[s_dst[r] + l] = a.tw[s_src[r] + l];
+        }
+        __syncthreads();
+        const int hw = threadIdx.x >> 5, l = threadIdx.x & 31;
+        constexpr int CU = 8;                                  // runs in flight per half-wave
+        for (int r0 = hw * CU; r0 < EXP_CHUNK; r0 += 8 * CU) {
+            uint32_t v[CU], w[CU];
+            bool ok[CU];
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                ok[u] = (uint32_t)l < (uint32_t)s_len[r0 + u];
+                v[u] = ok[u] ? a.rec[s_src[r0 + u] + l] : 0u;
+                w[u] = (ok[u] && a.o_tw) ? a.tw[s_src[r0 + u] + l] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                if (ok[u]) {
+                    a.o_rec[s_dst[r0 + u] + l] = v[u];
+                    if (a.o_tw) a.o_tw[s_dst[r0 + u] + l] = w[u];
                 }
             }
         }
@@ -2724,7 +2758,7 @@ extern "C" int otto_covis_export_plan(otto_covis_ctx* c, int n_owners, const uin
     a.totals = c->exp_totals.as<unsigned long long>();
     if (a.n_slots) {
         const int64_t nb = (a.n_slots + 255) / 256;
-        k_export_all<false><<<(unsigned)(nb < 256 * 16 ? nb : 256 * 16), 256, 0, s>>>(a);
+        k_export_plan<<<(unsigned)(nb < 256 * 8 ? nb : 256 * 8), 256, 0, s>>>(a);
         OTTO_HIP(hipGetLastError());
     }
     unsigned long long t[MAX_OWNERS];
@@ -2761,8 +2795,8 @@ extern "C" int otto_covis_export_fill(otto_covis_ctx* c, int n_owners, const uin
     a.rec = c->rec.as<uint32_t>();
     a.tw = c->tw.as<uint32_t>();
     a.o_hdr = d_hdr; a.o_rec = d_rec; a.o_tw = d_tw;
-    const int64_t nb = (a.n_slots + 255) / 256;
-    k_export_all<true><<<(unsigned)(nb < 256 * 16 ? nb : 256 * 16), 256, 0, s>>>(a);
+    const int64_t nb = (a.n_slots + EXP_CHUNK - 1) / EXP_CHUNK;
+    k_export_fill<<<(unsigned)(nb < 256 * 8 ? nb : 256 * 8), 256, 0, s>>>(a);
     OTTO_HIP(hipGetLastError());
     return 0;
 }
