@@ -128,6 +128,11 @@ int otto_covis_export_runs(otto_covis_ctx* ctx, uint32_t x_lo, uint32_t x_hi, ui
                            uint32_t* d_tw, void* stream);
 int otto_covis_import_runs(otto_covis_ctx* ctx, const uint32_t* d_hdr, int64_t n_runs, const uint32_t* d_rec,
                            const uint32_t* d_tw, int64_t n_recs, void* stream);
+/* Zero-copy receive: room for n_recs records (and time extras) at the end of the context's own record arrays.
+ * Let the all-to-all-v write there and pass exactly these pointers to otto_covis_import_runs: it then only
+ * registers the runs (no device copy). *d_tw is NULL without the time channel. The pointers stay valid until the
+ * next feed / import_reserve / reset. */
+int otto_covis_import_reserve(otto_covis_ctx* ctx, int64_t n_recs, uint32_t** d_rec, uint32_t** d_tw, void* stream);
 
 /* The same exchange in two passes over the runs for ALL owners at once: owner o holds aid_x in
  * [h_bounds[o], h_bounds[o+1]) (host array of n_owners+1 cut points, first/last treated as 0 / +inf).

@@ -70,6 +70,7 @@ SIGNATURES = {
     'otto_covis_export_count': (_i32, [_vp, _u32, _u32, _p_i64, _p_i64, _vp]),
     'otto_covis_export_runs': (_i32, [_vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     'otto_covis_import_runs': (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _vp]),
+    'otto_covis_import_reserve': (_i32, [_vp, _i64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp]),
     'otto_covis_export_plan': (_i32, [_vp, _i32, _vp, _p_i64, _p_i64, _vp]),
     'otto_covis_export_fill': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     'otto_covis_copy_records': (_i32, [_vp, _vp, _vp, _vp, _vp]),

@@ -18,14 +18,16 @@ def owner_bounds(n_aids, world):
     return [int(round(i * n_aids / world)) for i in range(world + 1)]
 
 
-def exchange_runs(export_fn, import_fn, bounds, group=None, want_time=False, stage_device=None, export_all_fn=None):
+def exchange_runs(export_fn, import_fn, bounds, group=None, want_time=False, stage_device=None, export_all_fn=None,
+                  reserve_fn=None):
     """Route runs to their aid_x owners with one all-to-all-v per array.
 
     ``export_all_fn(bounds) -> (hdr [n,2], rec, tw|None, runs_per_owner, recs_per_owner)`` (engine.export_all: every
     owner's piece already owner-major in one buffer) or, per owner, ``export_fn(lo, hi) -> (hdr, rec, tw|None)``;
     ``import_fn(hdr, rec, tw)`` on the owner engine.  ``stage_device`` (e.g. ``'cpu'`` with a gloo group): move the
     buffers there for the collectives and back -- used to rehearse the multi-rank path on a single GPU and in the
-    CPU tests; with nccl (= RCCL over xGMI) leave it None.
+    CPU tests; with nccl (= RCCL over xGMI) leave it None.  ``reserve_fn(n_recs) -> (rec, tw|None)`` (engine.import_reserve):
+    receive the records straight into the owner engine's arrays (no copy on import; ignored when staging).
     Returns (runs_sent, recs_sent, runs_received, recs_received).
     """
     import torch
@@ -51,18 +53,22 @@ def exchange_runs(export_fn, import_fn, bounds, group=None, want_time=False, sta
     sc = send_counts.cpu().numpy()
     rc = recv_counts.cpu().numpy()
 
-    def a2a(send, per_item, s_cnt, r_cnt):
-        recv = torch.empty(int(r_cnt.sum()) * per_item, dtype=torch.int32, device=dev)
+    inplace = (None, None)
+    if reserve_fn is not None and stage_device is None and int(rc[:, 1].sum()) > 0:
+        inplace = reserve_fn(int(rc[:, 1].sum()))
+
+    def a2a(send, per_item, s_cnt, r_cnt, out=None):
+        recv = out if out is not None else torch.empty(int(r_cnt.sum()) * per_item, dtype=torch.int32, device=dev)
         dist.all_to_all_single(recv, send.reshape(-1), [int(v) * per_item for v in r_cnt], [int(v) * per_item for v in s_cnt],
                                group=group)
         return recv
 
     hdr = a2a(hdr_s, 2, sc[:, 0], rc[:, 0]).reshape(-1, 2)
-    rec = a2a(rec_s, 1, sc[:, 1], rc[:, 1])
-    tw = a2a(tw_s, 1, sc[:, 1], rc[:, 1]) if want_time else None
+    rec = a2a(rec_s, 1, sc[:, 1], rc[:, 1], inplace[0])
+    tw = a2a(tw_s, 1, sc[:, 1], rc[:, 1], inplace[1]) if want_time else None
     if stage_device is not None:
         hdr, rec, tw = hdr.to(home), rec.to(home), None if tw is None else tw.to(home)
-    import_fn(hdr.contiguous(), rec.contiguous(), tw)
+    import_fn(hdr.contiguous(), rec if rec.is_contiguous() else rec.contiguous(), tw)
     return int(sc[:, 0].sum()), int(sc[:, 1].sum()), int(rc[:, 0].sum()), int(rc[:, 1].sum())
 
 
@@ -102,5 +108,6 @@ class ShardedCovisBuilder:
 
     def finalize(self, k=20, out=None):
         self.last_exchange = exchange_runs(self.local.export_runs, self.owner.import_runs, self.bounds, self.group,
-                                           self.local.want_time, self.stage_device, export_all_fn=self.local.export_all)
+                                           self.local.want_time, self.stage_device, export_all_fn=self.local.export_all,
+                                           reserve_fn=self.owner.import_reserve)
         return self.owner.finalize(k=k, out=out)

@@ -166,6 +166,23 @@ class CovisBuilder:
                        'otto_covis_export_fill')
         return hdr, rec, tw, runs, recs
 
+    def import_reserve(self, n_recs):
+        """Zero-copy receive buffers: int32 tensors (rec, tw|None) that alias the end of the context's own record arrays.
+        Fill them (e.g. as the output of the all-to-all-v) and hand them to ``import_runs``: no device copy is made."""
+        t = self.torch
+        pr, pt = C.c_void_p(), C.c_void_p()
+        with t.cuda.device(self.device):
+            _lib.check(self._lib.otto_covis_import_reserve(self._ctx, C.c_int64(int(n_recs)), C.byref(pr), C.byref(pt),
+                                                           self._stream()), 'otto_covis_import_reserve')
+
+        def wrap(ptr):
+            if not ptr or n_recs == 0:
+                return None
+            holder = type('_DevPtr', (), {'__cuda_array_interface__': {'shape': (int(n_recs),), 'typestr': '<i4',
+                                                                       'data': (int(ptr), False), 'version': 2}})()
+            return t.as_tensor(holder, device=self.device)
+        return wrap(pr.value), wrap(pt.value)
+
     def import_runs(self, hdr, rec, tw=None):
         t = self.torch
         with t.cuda.device(self.device):

@@ -2801,6 +2801,17 @@ extern "C" int otto_covis_export_fill(otto_covis_ctx* c, int n_owners, const uin
     return 0;
 }
 
+extern "C" int otto_covis_import_reserve(otto_covis_ctx* c, int64_t n_recs, uint32_t** d_rec, uint32_t** d_tw, void* stream) {
+    OTTO_REQUIRE(c && d_rec && d_tw && n_recs >= 0, "otto_covis_import_reserve: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)(n_recs > 0 ? n_recs : 1);
+    OTTO_TRY(c->rec.ensure((size_t)(c->rec_used + n) * 4, (size_t)c->rec_used * 4, s));
+    if (c->p.want_time) OTTO_TRY(c->tw.ensure((size_t)(c->rec_used + n) * 4, (size_t)c->rec_used * 4, s));
+    *d_rec = c->rec.as<uint32_t>() + c->rec_used;
+    *d_tw = c->p.want_time ? c->tw.as<uint32_t>() + c->rec_used : nullptr;
+    return 0;
+}
+
 extern "C" int otto_covis_import_runs(otto_covis_ctx* c, const uint32_t* d_hdr, int64_t n_runs, const uint32_t* d_rec,
                                       const uint32_t* d_tw, int64_t n_recs, void* stream) {
     OTTO_REQUIRE(c, "null ctx");
@@ -2815,8 +2826,10 @@ extern "C" int otto_covis_import_runs(otto_covis_ctx* c, const uint32_t* d_hdr, 
     if (c->p.want_time) OTTO_TRY(c->tw.ensure((size_t)(c->rec_used + n_recs) * 4, (size_t)c->rec_used * 4, s));
     OTTO_TRY(c->run_x.ensure((size_t)(c->run_used + n_runs) * 4, (size_t)c->run_used * 4, s));
     OTTO_TRY(c->run_desc.ensure((size_t)(c->run_used + n_runs) * 8, (size_t)c->run_used * 8, s));
-    OTTO_HIP(hipMemcpyAsync(c->rec.as<uint32_t>() + c->rec_used, d_rec, (size_t)n_recs * 4, hipMemcpyDeviceToDevice, s));
-    if (c->p.want_time)
+    // records received in place (otto_covis_import_reserve): nothing to copy
+    if (d_rec != c->rec.as<uint32_t>() + c->rec_used)
+        OTTO_HIP(hipMemcpyAsync(c->rec.as<uint32_t>() + c->rec_used, d_rec, (size_t)n_recs * 4, hipMemcpyDeviceToDevice, s));
+    if (c->p.want_time && d_tw != c->tw.as<uint32_t>() + c->rec_used)
         OTTO_HIP(hipMemcpyAsync(c->tw.as<uint32_t>() + c->rec_used, d_tw, (size_t)n_recs * 4, hipMemcpyDeviceToDevice, s));
     int grid = (int)((n_runs + 255) / 256 < 256 * 32 ? (n_runs + 255) / 256 : 256 * 32);
     k_import<<<grid, 256, 0, s>>>(d_hdr, n_runs, c->exp_rec_pos.as<uint64_t>(), c->rec_used, c->run_used,

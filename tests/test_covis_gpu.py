@@ -203,8 +203,16 @@ def test_multi_gpu_exchange_roundtrip(gpu_device):
     got = {k: [] for k in kinds}
     for x_lo, x_hi in ((0, cut), (cut, ev.n_aids)):
         owner = CovisBuilder(ev.n_aids, kinds=kinds, ts_min=ts_min, ts_max=ts_max, device=gpu_device)
-        for b in shards:
-            owner.import_runs(*b.export_runs(x_lo, x_hi))
+        for si, b in enumerate(shards):
+            hdr, rec, tw = b.export_runs(x_lo, x_hi)
+            if si == 1:
+                # zero-copy receive: the records land in the owner's own arrays (what the RCCL all-to-all-v writes
+                # into), import_runs then only registers the runs
+                rrec, rtw = owner.import_reserve(rec.numel())
+                rrec.copy_(rec)
+                rtw.copy_(tw)
+                rec, tw = rrec, rtw
+            owner.import_runs(hdr, rec, tw)
         out = owner.finalize(k=20)
         for k in kinds:
             gx, gy, gw = topk_to_rows(*out[k])
