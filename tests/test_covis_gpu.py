@@ -149,6 +149,29 @@ def test_heavy_aid_partitions_and_overflow_retry(gpu_device):
     _assert_rows_equal(got2, want, kinds)
 
 
+@pytest.mark.parametrize('n_sess', [4095, 4096, 9000])
+def test_packed_heavy_layout_counter_limit(gpu_device, n_sess):
+    """Heavy aids with fewer than 4096 runs use 12-bit packed counters (a pair gains at most one record per session
+    holding x). 4095 sessions that all hold (x, y) drive one counter to its maximum; with 4096 sessions the aid must
+    fall back to the wide layout. Both against the oracle, all kinds without a filter mask plus the filter kinds."""
+    rng = np.random.default_rng(n_sess)
+    n_aids = 30000
+    x, y = 7, 11
+    z = rng.integers(100, n_aids, size=(n_sess, 3)).astype(np.uint32)
+    aid = np.concatenate([np.full((n_sess, 1), x, np.uint32), np.full((n_sess, 1), y, np.uint32), z], axis=1)
+    ts = (1_660_000_000 + np.cumsum(rng.integers(1, 30, size=aid.shape), axis=1)).astype(np.int32)
+    typ = np.zeros(aid.shape, dtype=np.uint8)
+    typ[:, 2:] = rng.integers(0, 3, size=(n_sess, 3))
+    ev = Events(aid=aid.ravel(), ts=ts.ravel(), type=typ.ravel(), sess_off=np.arange(n_sess + 1, dtype=np.int64) * 5, n_aids=n_aids)
+    for kinds in (NOFILT, ('click_weighted', 'click_click', 'cart_order')):
+        want = _oracle_rows(ev, kinds)
+        b, got = _build(ev, gpu_device, kinds=kinds)
+        assert b.stats()['items_l'] >= 2          # x and y are heavy aids
+        _assert_rows_equal(got, want, kinds)
+        wx, wy, ww = want['click_weighted']
+        assert ww[(wx == x) & (wy == y)][0] == n_sess * 65536
+
+
 def test_chunked_feed_equals_single_feed(gpu_device):
     ev = generate_sessions(2500, n_aids=900, seed=21)
     _, one = _build(ev, gpu_device, chunks=1)
