@@ -2437,7 +2437,7 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
     } else if (bin == 1) {
         uint32_t grid = a.n_items < 256u * 4u ? a.n_items : 256u * 4u;
         tbegin(c, OTTO_COVIS_T_REDUCE_M, s);
-        k_reduce<M_LOG2T, M_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, (GROUP != OTTO_COVIS_GROUP_TIME ? 4 : 2), 4><<<grid, M_THREADS, 0, s>>>(a);
+        k_reduce<M_LOG2T, M_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, (GROUP != OTTO_COVIS_GROUP_TIME ? 4 : 2), 8><<<grid, M_THREADS, 0, s>>>(a);
         tend(c, OTTO_COVIS_T_REDUCE_M, s);
     } else {
         a.pstart = nullptr;

@@ -172,6 +172,21 @@ def test_packed_heavy_layout_counter_limit(gpu_device, n_sess):
         assert ww[(wx == x) & (wy == y)][0] == n_sess * 65536
 
 
+@pytest.mark.parametrize('options', [{'bucket_index': 0}, {'packed_heavy': 0}, {'guess': 0}, {'partition': 0},
+                                     {'packed_heavy': 0, 'guess': 0, 'bucket_index': 0, 'fused': 0}],
+                         ids=['atomic-index', 'wide-heavy', 'no-guess', 'no-partition', 'all-fallbacks'])
+def test_pipeline_options_agree(gpu_device, options):
+    """Every A/B switch of the pipeline (global-atomic index, wide layout for all heavy aids, no threshold guessing,
+    filtered re-reads instead of the partition pass) gives the oracle's rows on data with partitioned heavy aids."""
+    ev = generate_sessions(20000, n_aids=300, seed=23)
+    kinds = ('click_weighted', 'order_weighted', 'time_weighted')
+    want = _oracle_rows(ev, kinds)
+    b, got = _build(ev, gpu_device, kinds=kinds, options=options)
+    st = b.stats()
+    assert st['items_l'] > st['items_m'] + st['items_s'] or st['items_l'] > 100     # heavy aids dominate
+    _assert_rows_equal(got, want, kinds)
+
+
 def test_chunked_feed_equals_single_feed(gpu_device):
     ev = generate_sessions(2500, n_aids=900, seed=21)
     _, one = _build(ev, gpu_device, chunks=1)
