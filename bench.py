@@ -69,7 +69,7 @@ def algorithmic_bytes(st, k, nk):
     return out
 
 
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'round1', 'traffic_v2.json')
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'round1', 'traffic_v3.json')
 
 
 def pmc_traffic(substrings, full_otto):
@@ -244,8 +244,8 @@ def main():
         ksub = {'expand': ('k_expand',), 'index': ('k_bkt_',), 'partition': ('k_partition',),
                 'reduce_s': ('k_reduce<9,',), 'reduce_m': ('k_reduce<12,',), 'reduce_l': ('k_reduce<13,', 'k_reduce<14,')}
         knames = {'expand': 'k_expand_fused<false> (windows of 8 / 16 / 32 lanes, general and gap-free, one launch)',
-                  'reduce_s': 'k_reduce<9, 64, 0, true, 5, 8>', 'reduce_m': 'k_reduce<12, 256, 0, true, 4, 4>',
-                  'reduce_l': 'k_reduce<14, 1024, 0, true, 4, 2> (packed heavy aids) + k_reduce<13, 1024, 0, false, 4, 2> (wide)',
+                  'reduce_s': 'k_reduce<9, 64, 0, true, 5, 8>', 'reduce_m': 'k_reduce<12, 256, 0, true, 4, 8>',
+                  'reduce_l': 'k_reduce<14, 1024, 0, true, 4, 2> + k_reduce<13, 512, 0, true, 4, 4> (packed heavy aids) + k_reduce<13, 1024, 0, false, 4, 2> (wide)',
                   'partition': 'k_partition<false> + k_partition<true>',
                   'index': 'k_bkt_split<false/true> + k_bkt_local<false/true> + scans'}
         result = {
