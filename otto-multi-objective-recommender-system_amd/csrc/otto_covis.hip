@@ -1305,7 +1305,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     __shared__ uint32_t s_nex[PK];
     __shared__ uint32_t s_more;
     __shared__ uint32_t s_ovf;
-    __shared__ uint16_t s_list[NW == 1 ? 64 : 1];                              // one-wave bins: compacted valid slots
+    constexpr int LISTCAP = 256;
+    __shared__ uint16_t s_list[NW == 1 ? LISTCAP : 1];                         // one-wave bins: compacted valid slots
     __shared__ ItemDesc s_cur;
 
     const int wid = threadIdx.x >> 6;
@@ -1608,9 +1609,35 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                     const bool v = PACKED ? (s_tab[PACKED ? i : 0] != TAB_EMPTY) : (s_key[PACKED ? 0 : i] != KEY_EMPTY);
                     const uint64_t m = __ballot(v);
                     const uint32_t pos = nvalid + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (v && pos < 64u) s_list[pos] = (uint16_t)i;
+                    if (v && pos < (uint32_t)LISTCAP) s_list[pos] = (uint16_t)i;
                     nvalid += (uint32_t)__popcll(m);
                 }
+                // up to 256 keys: 2 or 4 per lane, built once and kept in registers; the selection (lane-best, interleaved
+                // sorts, threshold rounds) then runs on registers instead of re-reading and re-deriving the table slots
+                auto select_from_registers = [&](auto mtag) {
+                    constexpr int MC = decltype(mtag)::value;
+                    __syncthreads();
+                    K c[PKD][MC];
+#pragma unroll
+                    for (int q = 0; q < MC; ++q) {
+                        K kk[PKD];
+#pragma unroll
+                        for (int j = 0; j < PKD; ++j) kclear(kk[j]);
+                        const uint32_t li = (uint32_t)q * 64u + lane;
+                        if (li < nvalid) slot_keys((int)s_list[li], kk);
+#pragma unroll
+                        for (int j = 0; j < PKD; ++j) c[j][q] = kk[j];
+                    }
+                    K bests[PKD];
+                    wave_topk_select_multi<MC, PKD, K>(c, a.nk, a.k, bests);
+#pragma unroll
+                    for (int j = 0; j < PKD; ++j)
+                        if (j < a.nk) emit(j, bests[j]);
+                    compact_done = true;
+                    __syncthreads();
+                };
+                if (nvalid > 64u && nvalid <= 128u) select_from_registers(std::integral_constant<int, 2>{});
+                else if (nvalid > 128u && nvalid <= 256u) select_from_registers(std::integral_constant<int, 4>{});
                 if (nvalid <= 64u) {
                     __syncthreads();
                     K bests[PKD];
