@@ -1925,6 +1925,8 @@ __device__ __forceinline__ int owner_of(const OwnerArgs& a, uint32_t x) {
     return o;
 }
 
+constexpr int EXP_REC_BITS = 34;      // export totals / cursors per owner: runs << 34 | records (2^30 runs, 2^34 records)
+
 // plan: runs and records per owner. A streaming reduction: LDS accumulators live across the block's whole grid-stride
 // loop, one global atomic per owner and block at the end.
 __global__ __launch_bounds__(256) void k_export_plan(OwnerArgs a) {
@@ -1934,7 +1936,7 @@ __global__ __launch_bounds__(256) void k_export_plan(OwnerArgs a) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_slots; i += (int64_t)gridDim.x * 256) {
         const uint64_t d = a.run_desc[i];
         const uint32_t len = (uint32_t)(d & 0xFFull);
-        if (len) atomicAdd(&s_tot[owner_of(a, a.run_x[i])], (1ull << CNT_REC_BITS) | len);
+        if (len) atomicAdd(&s_tot[owner_of(a, a.run_x[i])], (1ull << EXP_REC_BITS) | len);
     }
     __syncthreads();
     if ((int)threadIdx.x < a.n_owners && s_tot[threadIdx.x]) atomicAdd(&a.totals[threadIdx.x], s_tot[threadIdx.x]);
@@ -1979,9 +1981,9 @@ __global__ __launch_bounds__(256) void k_export_fill(OwnerArgs a) {
             const unsigned long long r = s_rr[threadIdx.x] >> 32, c = s_rr[threadIdx.x] & 0xFFFFFFFFull;
             unsigned long long rb = 0, cb = 0;
             if (r) {
-                const unsigned long long old = atomicAdd(&a.totals[threadIdx.x], (r << CNT_REC_BITS) | c);
-                rb = old >> CNT_REC_BITS;
-                cb = old & CNT_REC_MASK;
+                const unsigned long long old = atomicAdd(&a.totals[threadIdx.x], (r << EXP_REC_BITS) | c);
+                rb = old >> EXP_REC_BITS;
+                cb = old & ((1ull << EXP_REC_BITS) - 1ull);
             }
             s_rbase[threadIdx.x] = rb;
             s_cbase[threadIdx.x] = cb;
@@ -2779,7 +2781,7 @@ extern "C" int otto_covis_export_plan(otto_covis_ctx* c, int n_owners, const uin
     hipStream_t s = (hipStream_t)stream;
     OwnerArgs a;
     OTTO_TRY(owner_args(c, n_owners, h_bounds, a));
-    OTTO_REQUIRE(c->run_used < (1ull << (64 - CNT_REC_BITS)) && c->rec_used < (1ull << CNT_REC_BITS), "too many runs for the packed export cursor");
+    OTTO_REQUIRE(c->run_used < (1ull << (64 - EXP_REC_BITS)) && c->rec_used < (1ull << EXP_REC_BITS), "too many runs for the packed export cursor");
     OTTO_TRY(c->exp_totals.ensure(2 * MAX_OWNERS * 8, 0, s));
     OTTO_HIP(hipMemsetAsync(c->exp_totals.p, 0, 2 * MAX_OWNERS * 8, s));
     a.totals = c->exp_totals.as<unsigned long long>();
@@ -2792,8 +2794,8 @@ extern "C" int otto_covis_export_plan(otto_covis_ctx* c, int n_owners, const uin
     OTTO_HIP(hipMemcpyAsync(t, c->exp_totals.p, sizeof t, hipMemcpyDeviceToHost, s));
     OTTO_HIP(hipStreamSynchronize(s));
     for (int o = 0; o < n_owners; ++o) {
-        c->exp_n_runs[o] = t[o] >> CNT_REC_BITS;
-        c->exp_n_recs[o] = t[o] & CNT_REC_MASK;
+        c->exp_n_runs[o] = t[o] >> EXP_REC_BITS;
+        c->exp_n_recs[o] = t[o] & ((1ull << EXP_REC_BITS) - 1ull);
         h_n_runs[o] = (int64_t)c->exp_n_runs[o];
         h_n_recs[o] = (int64_t)c->exp_n_recs[o];
     }

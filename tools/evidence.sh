@@ -1,3 +1,4 @@
+# Round evidence: GPU tests, bench under rocprofv3 --kernel-trace --stats, the two PMC passes, plain bench. Run with gpurun; copy the results into profiles/.
 set -e
 cd /root/repo
 export TMPDIR=/tmp
