@@ -708,7 +708,7 @@ struct BktArgs {
     uint32_t nb;
     uint32_t* bcount;              // [nb] runs per bucket, then the scatter cursors
     const uint64_t* bstart;        // [nb + 1]
-    uint64_t* tmp;                 // bucketed runs: descriptor (< 2^48) | aid_x within its bucket << 48
+    ulonglong2* tmp;               // bucketed runs {desc, aid_x}
     uint64_t* cnt64;
     const uint64_t* run_start;
     uint64_t* sorted_desc;
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(BKT_THREADS) void k_bkt_split(BktArgs a) {
                 if (xs[u] != 0xFFFFFFFFu) {
                     const uint32_t b = xs[u] >> a.sh;
                     const uint64_t pos = s_base[b] + atomicAdd(&s_cnt[b], 1u);
-                    a.tmp[pos] = ds[u] | ((uint64_t)(xs[u] & ((1u << a.sh) - 1u)) << 48);       // ONE 8-byte store per run
+                    a.tmp[pos] = make_ulonglong2(ds[u], (unsigned long long)xs[u]);     // one 16-byte store per run
                 }
             }
         }
@@ -790,9 +790,10 @@ __global__ __launch_bounds__(BKT_THREADS) void k_bkt_local(BktArgs a) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint64_t i = i0 + (uint64_t)u * BKT_THREADS;
-                const uint64_t r = i < e1 ? a.tmp[i] : 0ull;
-                d[u] = r & 0xFFFFFFFFFFFFull;
-                xl[u] = (uint32_t)(r >> 48);
+                ulonglong2 r = make_ulonglong2(0ull, 0ull);
+                if (i < e1) r = a.tmp[i];
+                d[u] = r.x;
+                xl[u] = (uint32_t)r.y - x0;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -2365,8 +2366,7 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
     memset(&ba, 0, sizeof ba);
     ba.sh = aid_bits > 22 ? aid_bits - 12 : 10;
     ba.nb = (uint32_t)(((uint64_t)n_aids + (1ull << ba.sh) - 1) >> ba.sh);
-    // <= 48 KB of LDS per bucket; descriptors below 2^48 leave 16 bits for the aid inside its bucket
-    const bool bucketed = c->bucket_index && n_slots > 0 && ba.nb <= (uint32_t)BKT_MAX_NB && ba.sh <= 12 && c->rec_used < (1ull << 40);
+    const bool bucketed = c->bucket_index && n_slots > 0 && ba.nb <= (uint32_t)BKT_MAX_NB && ba.sh <= 12;   // <= 48 KB of LDS per bucket
     if (bucketed) {
         ba.run_x = c->run_x.as<uint32_t>(); ba.run_desc = c->run_desc.as<uint64_t>();
         ba.n_slots = n_slots; ba.n_aids = n_aids;
@@ -2382,10 +2382,10 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
         uint64_t n_runs_b = 0;
         OTTO_HIP(hipMemcpyAsync(&n_runs_b, c->bstart.as<uint64_t>() + ba.nb, 8, hipMemcpyDeviceToHost, s));
         OTTO_HIP(hipStreamSynchronize(s));
-        OTTO_TRY(c->tmp_runs.ensure((size_t)(n_runs_b ? n_runs_b : 1) * 8, 0, s));
+        OTTO_TRY(c->tmp_runs.ensure((size_t)(n_runs_b ? n_runs_b : 1) * 16, 0, s));
         OTTO_HIP(hipMemsetAsync(c->bcount.p, 0, (size_t)ba.nb * 4, s));
         ba.bstart = c->bstart.as<uint64_t>();
-        ba.tmp = c->tmp_runs.as<uint64_t>();
+        ba.tmp = c->tmp_runs.as<ulonglong2>();
         k_bkt_split<true><<<sgrid, BKT_THREADS, 0, s>>>(ba);
         OTTO_HIP(hipGetLastError());
         ba.cnt64 = c->cnt64.as<uint64_t>();
