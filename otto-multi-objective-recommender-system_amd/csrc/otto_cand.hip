@@ -18,16 +18,9 @@
 
 namespace otto {
 
-constexpr int CD_THREADS = 256;
-constexpr int CD_NW = CD_THREADS / 64;
-constexpr int CD_MAXL = OTTO_CAND_MAX_SESSION;
-constexpr int CD_LOG2T = 12;
-constexpr int CD_T = 1 << CD_LOG2T;
-constexpr int CD_MPL = CD_T / CD_THREADS;            // table slots per thread
-constexpr int CD_CAP = 3072;                         // list entries per hash partition (load <= 3/4)
-constexpr int CD_MAXQ = OTTO_CAND_MAX_TERMS * CD_MAXL;
 constexpr uint64_t CD_EMPTY = ~0ull;
 constexpr int CD_EXCAP = 64;
+constexpr int CD_SMALL_MAXL = 32;                     // sessions up to this many events run in the small-footprint variant
 
 struct CandArgs {
     otto_cand_params p;
@@ -39,13 +32,22 @@ struct CandArgs {
     int32_t* count;
     int32_t* n_out;
     uint32_t* err;
+    int lo_len, hi_len;            // this launch handles sessions with lo_len <= events <= hi_len
 };
 
 __device__ __forceinline__ uint64_t cand_key(uint64_t count, uint32_t fp, uint32_t y) {
     return (count << 50) | ((uint64_t)(0xFFFFFFu - fp) << 26) | (uint64_t)y;
 }
 
+// Two instantiations share the code: <32, 10, 128> for short sessions (16 KB of LDS: ten workgroups per CU instead of
+// two -- most sessions are short and the per-session phases are barrier / latency bound) and <500, 12, 256> for the rest.
+template <int CD_MAXL, int CD_LOG2T, int CD_THREADS>
 __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
+    constexpr int CD_NW = CD_THREADS / 64;
+    constexpr int CD_T = 1 << CD_LOG2T;
+    constexpr int CD_CAP = CD_T / 4 * 3;                 // list entries per hash partition (load <= 3/4)
+    constexpr int CD_MAXQ = OTTO_CAND_MAX_TERMS * CD_MAXL;
+    static_assert(CD_THREADS >= OTTO_CAND_MAX_COMMON && CD_NW >= 2, "one carried entry per thread, two compaction waves");
     __shared__ uint32_t s_aid[CD_MAXL];
     __shared__ uint8_t s_ty[CD_MAXL];
     __shared__ uint8_t s_flag[CD_MAXL];               // bit0 last occurrence, bit1 first click/cart, bit2 first cart/order
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
     for (int64_t s = blockIdx.x; s < a.n_sess; s += gridDim.x) {
         const int64_t lo = a.sess_off[s], hi = a.sess_off[s + 1];
         const int n = (int)(hi - lo);
+        if (n < a.lo_len || n > a.hi_len) continue;        // the other variant's session
         if (n > CD_MAXL) {
             if (tid == 0) atomicAdd(a.err, 1u);
             continue;
@@ -128,6 +131,12 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
             running += tot;
         }
         const uint32_t TOT = running;
+        // table size follows the concatenation: most sessions are short, and clearing / scanning 4096 slots for a few
+        // hundred entries would dominate them
+        const int lt0 = TOT <= 192u ? 8 : (TOT <= 768u ? 10 : CD_LOG2T);
+        const int lt = lt0 < CD_LOG2T ? lt0 : CD_LOG2T;
+        const int Teff = 1 << lt;
+        const int mpl = Teff / CD_THREADS;                    // table slots per thread: 1, 4 or 16
         int lgR = 0;
         while (((uint32_t)CD_CAP << lgR) < TOT) ++lgR;
         __syncthreads();
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
         for (int i = tid; i < NC; i += CD_THREADS) s_sel[i] = 0;
         __syncthreads();
         for (uint32_t part = 0; part < R; ++part) {
-            for (int i = tid; i < CD_T; i += CD_THREADS) { s_tab[i] = CD_EMPTY; s_fp[i] = 0xFFFFFFFFu; }
+            for (int i = tid; i < Teff; i += CD_THREADS) { s_tab[i] = CD_EMPTY; s_fp[i] = 0xFFFFFFFFu; }
             __syncthreads();
             const int hw = tid >> 5, l = tid & 31;
             for (uint32_t q = hw; q < Q; q += CD_THREADS / 32) {
@@ -152,23 +161,20 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
                     const uint32_t x = s_src[a.p.term_source[t]][q - tstart[t]];
                     const uint32_t y = (uint32_t)a.p.d_mat_y[a.p.term_matrix[t]][(size_t)x * K + l];
                     const uint32_t h = y * 0x9E3779B1u;
-                    if (lgR == 0 || ((h >> (32 - CD_LOG2T - lgR)) & (R - 1u)) == part) {
-                        uint32_t slot = h >> (32 - CD_LOG2T);
+                    if (lgR == 0 || ((h >> (32 - lt - lgR)) & (R - 1u)) == part) {
+                        uint32_t slot = h >> (32 - lt);
                         bool placed = false;
-                        for (int probe = 0; probe < CD_T; ++probe) {
-                            const unsigned long long v = s_tab[slot];
-                            bool mine = v != CD_EMPTY && (uint32_t)(v >> 32) == y;
-                            if (v == CD_EMPTY) {
-                                const unsigned long long old = atomicCAS(&s_tab[slot], (unsigned long long)CD_EMPTY, (unsigned long long)y << 32);
-                                mine = old == CD_EMPTY || (uint32_t)(old >> 32) == y;
-                            }
-                            if (mine) {
-                                atomicAdd(&s_tab[slot], 1ull);
+                        for (int probe = 0; probe < Teff; ++probe) {
+                            // CAS first: a new aid goes in together with its first count
+                            const unsigned long long old = atomicCAS(&s_tab[slot], (unsigned long long)CD_EMPTY, ((unsigned long long)y << 32) | 1ull);
+                            const bool fresh = old == CD_EMPTY;
+                            if (fresh || (uint32_t)(old >> 32) == y) {
+                                if (!fresh) atomicAdd(&s_tab[slot], 1ull);
                                 atomicMin(&s_fp[slot], base + (uint32_t)l);
                                 placed = true;
                                 break;
                             }
-                            slot = (slot + 1) & (CD_T - 1);
+                            slot = (slot + 1) & (uint32_t)(Teff - 1);
                         }
                         if (!placed) s_ovf = 1;
                     }
@@ -180,17 +186,17 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
             auto cand_of = [&](int q) -> KeyN {
                 KeyN k;
                 k.c = 0;
-                if (q < CD_MPL) {
+                if (q < mpl) {
                     const int i = q * CD_THREADS + tid;
                     const unsigned long long v = s_tab[i];
                     if (v != CD_EMPTY) k.c = cand_key(v & 0xFFFFFFFFull, s_fp[i], (uint32_t)(v >> 32));
                 } else {
-                    const int i = tid + (q - CD_MPL) * CD_THREADS;
+                    const int i = tid + (q - mpl) * CD_THREADS;
                     if (part > 0 && i < NC) k.c = s_sel[i];
                 }
                 return k;
             };
-            constexpr int NCAND = CD_MPL + 1;                    // NC <= 128 <= CD_THREADS: one carried entry per thread
+            const int NCAND = mpl + 1;                           // NC <= 128 <= CD_THREADS: one carried entry per thread
             uint64_t selA = 0, selB = 0;                          // lane i of wave 0: i-th / (64+i)-th most common
             uint64_t limit = ~0ull;                               // round 2 only takes keys below the 64th of round 1
             for (int round = 0; round < 2; ++round) {
@@ -325,8 +331,13 @@ extern "C" int otto_cand_lookup(const otto_cand_params* p, const uint32_t* d_aid
     a.p = *p;
     a.aid = d_aid; a.type = d_type; a.sess_off = d_sess_off; a.n_sess = n_sess;
     a.cand = d_cand; a.count = d_count; a.n_out = d_n; a.err = d_err;
-    const int grid = (int)(n_sess < 256 * 8 ? n_sess : 256 * 8);
-    k_cand<<<grid, CD_THREADS, 0, s>>>(a);
+    // short sessions first (most of them), then the long ones; each variant skips the other's sessions
+    a.lo_len = 0; a.hi_len = CD_SMALL_MAXL;
+    const int grid_s = (int)(n_sess < 256 * 10 ? n_sess : 256 * 10);
+    k_cand<CD_SMALL_MAXL, 10, 128><<<grid_s, 128, 0, s>>>(a);
+    a.lo_len = CD_SMALL_MAXL + 1; a.hi_len = 0x7FFFFFFF;
+    const int grid = (int)(n_sess < 256 * 2 ? n_sess : 256 * 2);
+    k_cand<OTTO_CAND_MAX_SESSION, 12, 256><<<grid, 256, 0, s>>>(a);
     hipError_t le = hipGetLastError();
     uint32_t err = 0;
     hipError_t ce = hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s);
