@@ -37,6 +37,16 @@ class CandParams(C.Structure):
     ]
 
 
+class RecencyParams(C.Structure):
+    # mirrors otto_recency_params (include/otto_cand.h)
+    _fields_ = [
+        ('n_curves', C.c_int32),
+        ('start', C.c_double * 4),
+        ('stop', C.c_double * 4),
+        ('type_coef', C.c_double * 3),
+    ]
+
+
 class CovisParams(C.Structure):
     # mirrors otto_covis_params (include/otto_covis.h)
     _fields_ = [
@@ -78,6 +88,7 @@ SIGNATURES = {
     'otto_debug_calibrate': (_i32, [_vp, _i64, _i32, _vp]),
     # include/otto_cand.h
     'otto_cand_lookup': (_i32, [C.POINTER(CandParams), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    'otto_recency_candidates': (_i32, [C.POINTER(RecencyParams), _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     # include/otto_mf.h
     'otto_mf_create': (_i32, [C.POINTER(_vp), _i64, _i64, _i32, _i64, _i32]),
     'otto_mf_destroy': (None, [_vp]),

@@ -49,3 +49,39 @@ def candidate_lookup(aid, typ, sess_off, matrices, recipe, n_common=100):
                                                C.c_void_p(count.data_ptr()), C.c_void_p(n_out.data_ptr()),
                                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), 'otto_cand_lookup')
     return cand, count, n_out
+
+
+# curves and type coefficients of src/ranker/recency_weighted_candidate_generator.py:24,68-70
+RECENCY_CURVES = ((0.1, 1.0), (0.5, 1.0))            # clicks; carts and orders
+RECENCY_TYPE_COEFFICIENT = (1.0, 6.0, 1.0)
+
+
+def recency_candidates(aid, typ, sess_off, curves=RECENCY_CURVES, type_coef=RECENCY_TYPE_COEFFICIENT):
+    """Recency-weighted candidates of every session (the loop of
+    ``src/ranker/recency_weighted_candidate_generator.py:61-93``).  Returns (cand int32 [n_curves, E], weight float64
+    [n_curves, E], n int32 [S]): session s owns ``[sess_off[s], sess_off[s] + n[s])`` of every curve's row, in
+    ``Counter.most_common`` order."""
+    import torch
+    dev = aid.device
+    if dev.type != 'cuda':
+        raise _lib.OttoError('recency_candidates needs a ROCm device (no CPU fallback)')
+    for name, x, dt in (('aid', aid, torch.int32), ('type', typ, torch.uint8), ('sess_off', sess_off, torch.int64)):
+        if x.dtype != dt or not x.is_contiguous():
+            raise ValueError(f'{name}: expected contiguous {dt}')
+    p = _lib.RecencyParams()
+    p.n_curves = len(curves)
+    for c, (a0, a1) in enumerate(curves):
+        p.start[c], p.stop[c] = float(a0), float(a1)
+    for t in range(3):
+        p.type_coef[t] = float(type_coef[t])
+    S, E = sess_off.numel() - 1, aid.numel()
+    cand = torch.full((len(curves), E), -1, dtype=torch.int32, device=dev)
+    w = torch.zeros((len(curves), E), dtype=torch.float64, device=dev)
+    n_out = torch.zeros(S, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().otto_recency_candidates(C.byref(p), C.c_void_p(aid.data_ptr()), C.c_void_p(typ.data_ptr()),
+                                                      C.c_void_p(sess_off.data_ptr()), S, E, C.c_void_p(cand.data_ptr()),
+                                                      C.c_void_p(w.data_ptr()), C.c_void_p(n_out.data_ptr()),
+                                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                   'otto_recency_candidates')
+    return cand, w, n_out

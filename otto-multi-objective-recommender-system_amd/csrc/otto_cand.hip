@@ -303,9 +303,126 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
     }
 }
 
+// ---- recency-weighted candidates (section 8 f3) ------------------------------------------------------------------
+struct RecencyArgs {
+    otto_recency_params p;
+    const uint32_t* aid;
+    const uint8_t* type;
+    const int64_t* sess_off;
+    int64_t n_sess;
+    int64_t n_events;
+    int32_t* out_aid;
+    double* out_w;
+    int32_t* n_out;
+    uint32_t* err;
+    int lo_len, hi_len;
+};
+
+// One workgroup per session (THREADS = 64 for sessions up to 64 events, 256 beyond). Event i: weight of every curve
+// (NumPy's linspace arithmetic: i * step + start, two roundings, last element = stop), first-occurrence flag; a first
+// occurrence sums its aid's weighted events in session order (what Counter += does) and ranks itself among the
+// other first occurrences by (weight desc, first position asc) = Counter.most_common's stable order.
+template <int MAXL, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_recency(RecencyArgs a) {
+    __shared__ uint32_t s_aid[MAXL];
+    __shared__ double s_wc[OTTO_RECENCY_MAX_CURVES][MAXL];     // curve weight x type coefficient of event i
+    __shared__ double s_acc[OTTO_RECENCY_MAX_CURVES][MAXL];    // Counter value of the aid first seen at i
+    __shared__ uint8_t s_first[MAXL];
+    __shared__ uint32_t s_nu;
+    const int tid = threadIdx.x;
+    const int NCV = a.p.n_curves;
+    for (int64_t s = blockIdx.x; s < a.n_sess; s += gridDim.x) {
+        const int64_t lo = a.sess_off[s], hi = a.sess_off[s + 1];
+        const int n = (int)(hi - lo);
+        if (n < a.lo_len || n > a.hi_len) continue;
+        if (n > MAXL) {
+            if (tid == 0) atomicAdd(a.err, 1u);
+            continue;
+        }
+        if (tid == 0) s_nu = 0;
+        for (int i = tid; i < n; i += THREADS) {
+            s_aid[i] = a.aid[lo + i];
+            const uint32_t ty = a.type[lo + i];
+            const double coef = ty < 3u ? a.p.type_coef[ty] : 0.0;
+            for (int c = 0; c < NCV; ++c) {
+                const double start = a.p.start[c], stop = a.p.stop[c];
+                double y = start;
+                if (n > 1) {
+                    const double step = __ddiv_rn(__dsub_rn(stop, start), (double)(n - 1));
+                    y = i == n - 1 ? stop : __dadd_rn(__dmul_rn((double)i, step), start);
+                }
+                s_wc[c][i] = __dmul_rn(__dsub_rn(exp2(y), 1.0), coef);
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += THREADS) {
+            const uint32_t ai = s_aid[i];
+            bool first = true;
+            for (int j = 0; j < i; ++j) first = first && s_aid[j] != ai;
+            s_first[i] = first ? 1 : 0;
+            if (first) {
+                atomicAdd(&s_nu, 1u);
+                for (int c = 0; c < NCV; ++c) {
+                    double acc = 0.0;
+                    for (int j = i; j < n; ++j)
+                        if (s_aid[j] == ai) acc = __dadd_rn(acc, s_wc[c][j]);
+                    s_acc[c][i] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += THREADS) {
+            if (!s_first[i]) continue;
+            for (int c = 0; c < NCV; ++c) {
+                const double wi = s_acc[c][i];
+                int rank = 0;
+                for (int r = 0; r < n; ++r)
+                    if (s_first[r] && (s_acc[c][r] > wi || (s_acc[c][r] == wi && r < i))) ++rank;
+                const size_t o = (size_t)c * (size_t)a.n_events + (size_t)lo + (size_t)rank;
+                a.out_aid[o] = (int32_t)s_aid[i];
+                a.out_w[o] = wi;
+            }
+        }
+        if (tid == 0) a.n_out[s] = (int32_t)s_nu;
+        __syncthreads();
+    }
+}
+
 }  // namespace otto
 
 using namespace otto;
+
+extern "C" int otto_recency_candidates(const otto_recency_params* p, const uint32_t* d_aid, const uint8_t* d_type,
+                                       const int64_t* d_sess_off, int64_t n_sess, int64_t n_events, int32_t* d_out_aid,
+                                       double* d_out_w, int32_t* d_n, void* stream) {
+    OTTO_REQUIRE(p && d_sess_off && d_out_aid && d_out_w && d_n, "otto_recency_candidates: null argument");
+    OTTO_REQUIRE(p->n_curves >= 1 && p->n_curves <= OTTO_RECENCY_MAX_CURVES, "n_curves must be in [1, %d]", OTTO_RECENCY_MAX_CURVES);
+    OTTO_REQUIRE(n_events >= 0, "n_events < 0");
+    if (n_sess <= 0) return 0;
+    OTTO_REQUIRE(d_aid && d_type, "null event arrays");
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t* d_err = nullptr;
+    OTTO_HIP(hipMalloc(&d_err, 4));
+    OTTO_HIP(hipMemsetAsync(d_err, 0, 4, s));
+    RecencyArgs a;
+    memset(&a, 0, sizeof a);
+    a.p = *p;
+    a.aid = d_aid; a.type = d_type; a.sess_off = d_sess_off; a.n_sess = n_sess; a.n_events = n_events;
+    a.out_aid = d_out_aid; a.out_w = d_out_w; a.n_out = d_n; a.err = d_err;
+    a.lo_len = 0; a.hi_len = 64;
+    k_recency<64, 64><<<(int)(n_sess < 256 * 32 ? n_sess : 256 * 32), 64, 0, s>>>(a);
+    a.lo_len = 65; a.hi_len = 0x7FFFFFFF;
+    k_recency<OTTO_CAND_MAX_SESSION, 256><<<(int)(n_sess < 256 * 8 ? n_sess : 256 * 8), 256, 0, s>>>(a);
+    hipError_t le = hipGetLastError();
+    uint32_t h_err = 0;
+    if (le == hipSuccess) le = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, s);
+    if (le == hipSuccess) le = hipStreamSynchronize(s);
+    (void)hipFree(d_err);
+    if (le != hipSuccess) { set_error("otto_recency_candidates: %s", hipGetErrorString(le)); return -5; }
+    OTTO_REQUIRE(h_err == 0, "%u session(s) longer than %d events", h_err, OTTO_CAND_MAX_SESSION);
+    return 0;
+}
+
 
 extern "C" int otto_cand_lookup(const otto_cand_params* p, const uint32_t* d_aid, const uint8_t* d_type, const int64_t* d_sess_off,
                                 int64_t n_sess, int32_t* d_cand, int32_t* d_count, int32_t* d_n, void* stream) {

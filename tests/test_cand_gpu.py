@@ -64,3 +64,29 @@ def test_candidates_long_sessions_use_hash_partitions(gpu_device):
     typ = rng.integers(0, 3, off[-1]).astype(np.uint8)
     val = Events(aid=aid, ts=np.zeros(off[-1], dtype=np.int32), type=typ, sess_off=off, n_aids=5000)
     _check(ev, val, gpu_device, (cdo.CLICK_RECIPE, cdo.ORDER_RECIPE))
+
+
+def test_recency_weighted_candidates_match_reference_loop(gpu_device):
+    """Section 8 f3: order identical to Counter.most_common, float64 weights within 1e-12 relative (the device exp2 may
+    differ from NumPy's pow in the last unit). Sessions of 1 event, of one repeated aid, and of 300+ events included."""
+    import torch
+    import recency_oracle as ro
+    from otto_amd.covisitation.candidates import recency_candidates
+    rng = np.random.default_rng(12)
+    ev = generate_sessions(3000, n_aids=400, seed=15)
+    L = np.r_[np.diff(ev.sess_off), [1, 1, 9, 320, 64, 65, 2]]
+    off = np.r_[0, np.cumsum(L)].astype(np.int64)
+    extra = int(off[-1] - ev.sess_off[-1])
+    aid = np.r_[ev.aid, rng.integers(0, 400, extra).astype(np.uint32)]
+    typ = np.r_[ev.type, rng.integers(0, 3, extra).astype(np.uint8)]
+    aid[off[-6]:off[-5]] = 33                                     # the 9-event session repeats one aid
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(gpu_device)
+    cand, w, n = recency_candidates(t(aid, np.int32), t(typ, np.uint8), t(off, np.int64))
+    cand, w, n = cand.cpu().numpy(), w.cpu().numpy(), n.cpu().numpy()
+    want = ro.all_recency(aid, typ, off)
+    for s, per_curve in enumerate(want):
+        lo = int(off[s])
+        for c, (wa, ww) in enumerate(per_curve):
+            assert n[s] == len(wa), f'session {s}: {n[s]} unique aids vs {len(wa)}'
+            assert cand[c, lo:lo + n[s]].tolist() == wa, f'session {s} curve {c}: order differs'
+            np.testing.assert_allclose(w[c, lo:lo + n[s]], np.array(ww), rtol=1e-12, atol=0)

@@ -133,3 +133,15 @@ def test_item_table_delta_allreduce_world2():
     want[3] += 1.0
     for r in range(2):
         assert np.array_equal(res[r][0], want) and np.array_equal(res[r][1], want)
+
+
+def test_recency_oracle_hand_example():
+    """oracle/recency_oracle.py on a hand-computed session: aids (5, 7, 5), types (click, cart, click).
+    click curve 2^linspace(0.1, 1, 3) - 1 = (2^0.1 - 1, 2^0.55 - 1, 1); Counter: 5 -> w0 + w2, 7 -> 6 * w1."""
+    import recency_oracle as ro
+    (aids, weights), (aids2, _) = ro.session_recency([5, 7, 5], [0, 1, 0])
+    w = 2.0 ** np.linspace(0.1, 1.0, 3) - 1
+    assert aids == [7, 5] and np.allclose(weights, [6 * w[1], w[0] + w[2]], rtol=1e-15)
+    assert aids2 == [7, 5]
+    (a1, w1), _ = ro.session_recency([9], [2])
+    assert a1 == [9] and np.isclose(w1[0], 2.0 ** 0.1 - 1)

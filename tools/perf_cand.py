@@ -29,3 +29,9 @@ for name, recipe in (('click', cd.CLICK_RECIPE), ('cart', cd.CART_RECIPE), ('ord
         cand, cnt, n = cd.candidate_lookup(v['aid'], v['type'], v['sess_off'], mats, recipe)
         torch.cuda.synchronize(); t1 = time.time()
     print(f'{name}: {1e3*(t1-t0):.2f} ms  {a.sessions/(t1-t0):.3e} sessions/s  mean candidates {n.float().mean().item():.1f}', flush=True)
+
+for r in range(a.reps):
+    torch.cuda.synchronize(); t0 = time.time()
+    rc, rw, rn = cd.recency_candidates(v['aid'], v['type'], v['sess_off'])
+    torch.cuda.synchronize(); t1 = time.time()
+print(f'recency: {1e3*(t1-t0):.2f} ms  {a.sessions/(t1-t0):.3e} sessions/s  mean unique aids {rn.float().mean().item():.1f}', flush=True)
