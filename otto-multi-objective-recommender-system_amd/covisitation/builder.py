@@ -71,18 +71,17 @@ def write_parts(directory, prefix, kind, rows, n_parts, n_aids):
 
 
 def build_matrices(ev, kinds=REFERENCE_KINDS, ks=(15, 20), device='cuda:0', window=30, max_gap=86400,
-                   chunk_sessions=4_000_000):
+                   chunk_sessions=2_000_000):
     """Events -> {k: {kind: (aid_x, aid_y, W)}} rows in (aid_x, rank) order, via the HIP engine."""
     import torch
     from .engine import CovisBuilder, topk_to_rows
     dev = torch.device(device)
     b = CovisBuilder(ev.n_aids, kinds=kinds, window=window, max_gap=max_gap,
                      ts_min=int(ev.ts.min()) if ev.n_events else 0, ts_max=int(ev.ts.max()) if ev.n_events else 0, device=dev)
-    for lo in range(0, ev.n_sessions, chunk_sessions):
-        hi = min(ev.n_sessions, lo + chunk_sessions)
-        e0, e1 = int(ev.sess_off[lo]), int(ev.sess_off[hi])
-        b.feed(torch.from_numpy(ev.aid[e0:e1].astype(np.int32)).to(dev), torch.from_numpy(ev.ts[e0:e1]).to(dev),
-               torch.from_numpy(ev.type[e0:e1]).to(dev), torch.from_numpy(ev.sess_off[lo:hi + 1] - e0).to(dev))
+    from ..ingest import feed_host_events
+    with torch.cuda.device(dev):
+        seconds, nbytes = feed_host_events(b, ev, dev, chunk_sessions=chunk_sessions)      # pinned, double-buffered H2D
+    logging.info(f'ingest: {nbytes / 1e9:.2f} GB host -> device + pair expansion in {seconds:.3f} s')
     kmax = max(ks)
     out = b.finalize(k=kmax)
     res = {}

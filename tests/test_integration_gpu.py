@@ -167,3 +167,28 @@ def test_bpr_training_improves_recall_at_20(gpu_device):
     r1 = recall()
     assert losses[-1] < 0.5 * losses[0]
     assert r1 > 5 * max(r0, 20 / n_items) and r1 > 0.12
+
+
+def test_streamed_host_ingest_equals_device_feed(gpu_device):
+    """Section 8 f2: pinned, double-buffered host -> device ingest (several chunks, odd sizes) gives the same matrices as
+    one feed of device-resident arrays."""
+    import numpy as np
+    import torch
+    from otto_amd.synth import generate_sessions
+    from otto_amd.ingest import feed_host_events
+    from otto_amd.covisitation.engine import CovisBuilder, topk_to_rows
+    kinds = ('click_weighted', 'time_weighted', 'cart_order')
+    ev = generate_sessions(5000, n_aids=800, seed=77)
+    mk = lambda: CovisBuilder(ev.n_aids, kinds=kinds, ts_min=int(ev.ts.min()), ts_max=int(ev.ts.max()), device=gpu_device)
+    a = mk()
+    a.feed(torch.from_numpy(ev.aid.astype(np.int32)).to(gpu_device), torch.from_numpy(ev.ts).to(gpu_device),
+           torch.from_numpy(ev.type).to(gpu_device), torch.from_numpy(ev.sess_off).to(gpu_device))
+    want = a.finalize(k=20)
+    b = mk()
+    with torch.cuda.device(gpu_device):
+        seconds, nbytes = feed_host_events(b, ev, gpu_device, chunk_sessions=777)
+    assert nbytes >= 9 * ev.n_events
+    got = b.finalize(k=20)
+    for kind in kinds:
+        for g, w in zip(topk_to_rows(*got[kind]), topk_to_rows(*want[kind])):
+            assert np.array_equal(g, w), kind
