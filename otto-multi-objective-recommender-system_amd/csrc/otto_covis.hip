@@ -4,16 +4,19 @@
 // (SURVEY.md F1); the only related reference code is the session self-join of
 // src/matrix_factorization/torch_trainer.py:198-223.
 //
-// Pipeline (DESIGN.md "Covisitation kernels"):
+// Pipeline:
 //   winscan  : per session n = min(len, W); exclusive scans of n(n-1) (record slots) and n (run slots)
-//   K1 expand: one 32-lane half-wave per session window; class ids, LDS atomicMin matrix
-//              M[class_x][class_y] = first valid (i,j); emit one 4-byte record per deduped pair,
-//              grouped by aid_x inside the window (a "run"), plus one run descriptor per window event
-//   index    : histogram of runs per aid_x (one 64-bit atomic per run), scan, scatter of run descriptors,
-//              work-item lists in three size bins (S/M/L; L items are hash partitions of one heavy aid_x)
-//   K2 reduce: per work item gather the runs' records, aggregate by aid_y in an LDS hash table
-//              (no global atomics), then block-wide top-k per kind; heavy aids: partial top-k per
-//              partition + exact merge
+//   K1 expand: no filter kinds -> k_expand_fused: one launch over the sessions in memory order, windows of 8 / 16 / 32
+//              lanes held in registers, row loop with wave-mask predicates, gap-free shortcut; filter kinds ->
+//              class-sorted k_expand / k_expand_fast with the LDS ds_min matrix M[class_x][class_y] and filter bits.
+//              Either way: one 4-byte record per deduped pair, grouped by aid_x inside the window (a "run"), plus
+//              one run descriptor per window event
+//   index    : runs split into buckets of 1024 consecutive aids, then counted and placed per bucket with LDS atomics
+//              (k_bkt_*; fallback: one 64-bit memory-side atomic per run, k_hist_runs / k_scatter_runs); work-item
+//              lists in three size bins (S/M/L; L items are hash partitions of one heavy aid_x, three table layouts)
+//   K2 reduce: per work item gather the runs' records (or read the partition bucket), aggregate by aid_y in an LDS
+//              hash table (no global atomics), then top-k per kind; heavy aids: partial top-k per partition (one pass
+//              when a sibling partition's threshold is known) + exact merge
 #include "common.h"
 #include "topk.h"
 #include "../../include/otto_covis.h"
