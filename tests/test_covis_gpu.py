@@ -260,6 +260,35 @@ def test_multi_gpu_exchange_roundtrip(gpu_device):
     _assert_rows_equal(merged, want, kinds)
 
 
+def test_sharded_builder_over_rccl_world_of_one(gpu_device):
+    """The N > 1 code path of bench.py over the real RCCL backend with a world of one process: the all-to-all-v writes the
+    records straight into the owner context (otto_covis_import_reserve), no staging. Rows == single-context build."""
+    import socket
+    import torch.multiprocessing as mp
+    from conftest import ROOT
+    ev = generate_sessions(3000, n_aids=900, seed=61)
+    _, want = _build(ev, gpu_device)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_sharded_worker, args=(0, 1, port, q, ROOT, 'nccl'))
+    p.start()
+    import queue
+    res = None
+    for _ in range(120):                       # poll: a crashed worker must not stall the suite
+        try:
+            res = q.get(timeout=1)
+            break
+        except queue.Empty:
+            if not p.is_alive():
+                break
+    p.join(60)
+    assert res is not None and p.exitcode == 0, f'RCCL worker failed (exit code {p.exitcode})'
+    _assert_rows_equal(res[2], want, cs.ALL_KINDS)
+
+
 def test_deterministic_across_runs(gpu_device):
     ev = generate_sessions(4000, n_aids=1500, seed=51)
     _, a = _build(ev, gpu_device)
@@ -285,7 +314,7 @@ def test_golden_fixture_and_hand_computed_sessions(gpu_device):
         assert d == ({p: w * cs.Q16 for p, w in want.items()} if want is not None else HAND_TIME), kind
 
 
-def _sharded_worker(rank, world, port, q, root):
+def _sharded_worker(rank, world, port, q, root, backend='gloo'):
     import os
     import sys
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -294,8 +323,9 @@ def _sharded_worker(rank, world, port, q, root):
     import torch.distributed as dist
     from otto_amd.covisitation.distributed import ShardedCovisBuilder, global_ts_range
     from otto_amd.covisitation.engine import topk_to_rows
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
     ev = generate_sessions(3000, n_aids=900, seed=61)
     per = ev.n_sessions // world
     lo, hi = rank * per, ev.n_sessions if rank == world - 1 else (rank + 1) * per
@@ -304,8 +334,9 @@ def _sharded_worker(rank, world, port, q, root):
     ts = torch.from_numpy(ev.ts[e0:e1]).to(dev)
     typ = torch.from_numpy(ev.type[e0:e1]).to(dev)
     off = torch.from_numpy(ev.sess_off[lo:hi + 1] - e0).to(dev)
-    ts_min, ts_max = global_ts_range(ts.cpu())
-    b = ShardedCovisBuilder(ev.n_aids, cs.ALL_KINDS, ts_min, ts_max, dev, stage_device='cpu')
+    ts_min, ts_max = global_ts_range(ts.cpu() if backend == 'gloo' else ts)
+    # gloo: pieces staged through host memory; nccl (= RCCL): device buffers, records received in place
+    b = ShardedCovisBuilder(ev.n_aids, cs.ALL_KINDS, ts_min, ts_max, dev, stage_device='cpu' if backend == 'gloo' else None)
     out_rows = None
     for _ in range(2):                      # twice: reset() must leave no state behind (bench loops like this)
         b.reset()
