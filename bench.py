@@ -92,6 +92,40 @@ def roofline_obj(name, ms, nbytes, traffic=None):
             'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'avg_ms': round(ms, 4), 'algorithmic_bytes': int(nbytes)}
 
 
+def candidates_leg(data, dev, n_aids, train_sessions=3_000_000, sessions=1_800_000):
+    """Candidate lookup (click recipe, most_common(100)) and recency-weighted candidates over a validation-sized session
+    set; the five matrices come from a build over the first ``train_sessions`` sessions of the bench stream."""
+    import torch
+    from otto_amd.covisitation.engine import CovisBuilder
+    from otto_amd.covisitation import candidates as cd
+    S = data['sess_off'].numel() - 1
+    train_sessions, sessions = min(train_sessions, S), min(sessions, S)
+    off = data['sess_off'][:train_sessions + 1].contiguous()
+    e = int(off[-1])
+    kinds = ('time_weighted', 'click_weighted', 'cart_weighted', 'click_cart', 'cart_order')
+    b = CovisBuilder(n_aids, kinds=kinds, ts_min=int(data['ts'].min()), ts_max=int(data['ts'].max()), device=dev)
+    b.feed(data['aid'][:e].contiguous(), data['ts'][:e].contiguous(), data['type'][:e].contiguous(), off)
+    mats = b.finalize(k=15)
+    del b
+    lo = S - sessions                                            # the last sessions of the stream stand in for validation
+    voff = (data['sess_off'][lo:] - data['sess_off'][lo]).contiguous()
+    e0 = int(data['sess_off'][lo])
+    vaid, vtyp = data['aid'][e0:].contiguous(), data['type'][e0:].contiguous()
+    out = {}
+    for name, fn in (('lookup_click_recipe', lambda: cd.candidate_lookup(vaid, vtyp, voff, mats, cd.CLICK_RECIPE)),
+                     ('recency', lambda: cd.recency_candidates(vaid, vtyp, voff))):
+        fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.time()
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        ms = 1e3 * (time.time() - t0) / 3
+        out[name] = {'ms': round(ms, 2), 'sessions_per_s': round(sessions / (ms * 1e-3), 1)}
+    out['config'] = f'{sessions} sessions, {int(vaid.numel())} events, top-15 matrices from {train_sessions} sessions'
+    return out
+
+
 def cpu_baseline(dev_data, n_sessions, k):
     """Time the CPU restatement (oracle/, kind 'port') on the first n_sessions of the same stream."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -285,6 +319,12 @@ def main():
                               (lambda subs: pmc_traffic(subs, world == 1 and a.sessions == 14_571_582)))
             if rank == 0:
                 result['mf'] = mf
+    # ---- the callers either side of the path, N = 1 only: candidate lookup + recency ----
+    if rank == 0 and world == 1 and not a.no_mf:
+        try:
+            result['candidates'] = candidates_leg(data, dev, n_aids)
+        except Exception as e:                                   # a reported extra, never a reason to lose the bench line
+            result['candidates'] = {'error': repr(e)}
     if rank == 0 and world == 1 and a.cpu_sessions > 0:
         result['cpu_baseline'] = cpu_baseline(data, min(a.cpu_sessions, a.sessions), a.k)
     if rank == 0:
