@@ -134,7 +134,8 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
         // table size follows the concatenation: most sessions are short, and clearing / scanning 4096 slots for a few
         // hundred entries would dominate them
         const int lt0 = TOT <= 192u ? 8 : (TOT <= 768u ? 10 : CD_LOG2T);
-        const int lt = lt0 < CD_LOG2T ? lt0 : CD_LOG2T;
+        const int lt1 = lt0 < CD_LOG2T ? lt0 : CD_LOG2T;
+        const int lt = (1 << lt1) < CD_THREADS ? CD_LOG2T : lt1;       // at least one table slot per thread
         const int Teff = 1 << lt;
         const int mpl = Teff / CD_THREADS;                    // table slots per thread: 1, 4 or 16
         int lgR = 0;
@@ -454,7 +455,7 @@ extern "C" int otto_cand_lookup(const otto_cand_params* p, const uint32_t* d_aid
     k_cand<CD_SMALL_MAXL, 10, 128><<<grid_s, 128, 0, s>>>(a);
     a.lo_len = CD_SMALL_MAXL + 1; a.hi_len = 0x7FFFFFFF;
     const int grid = (int)(n_sess < 256 * 2 ? n_sess : 256 * 2);
-    k_cand<OTTO_CAND_MAX_SESSION, 12, 256><<<grid, 256, 0, s>>>(a);
+    k_cand<OTTO_CAND_MAX_SESSION, 12, 512><<<grid, 512, 0, s>>>(a);
     hipError_t le = hipGetLastError();
     uint32_t err = 0;
     hipError_t ce = hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s);
