@@ -111,9 +111,16 @@ int otto_covis_finalize(otto_covis_ctx* ctx, int group, int k, uint32_t* d_out_y
 
 int otto_covis_stats(otto_covis_ctx* ctx, int64_t* out /* [OTTO_COVIS_STAT_COUNT] */);
 
-/* Tuning knobs; results are exact for every value.
- *   "l_cap": expanded pairs per hash partition of a heavy aid_x (default 6144);
- *   "partition": 1 (default) bucket heavy aids' pairs by partition once, 0 re-read and filter per partition */
+/* Tuning knobs and A/B switches; results are exact for every value (each is exercised by tests/test_covis_gpu.py).
+ *   "l_cap": expanded pairs per hash partition of a heavy aid_x in the wide table layout (default 6144; the packed
+ *            2^14-slot layout takes twice as many);
+ *   "partition": 1 (default) bucket heavy aids' pairs by partition once, 0 re-read and filter per partition;
+ *   "fused": 1 (default) fused in-order register pair-expand kernel when no filter kind is configured, 0 class-sorted kernels;
+ *   "fast_path": 1 (default) gap-free window shortcut in the pair-expand kernels;
+ *   "bucket_index": 1 (default) group the runs by aid_x with LDS atomics per 1024-aid bucket, 0 one global atomic per run;
+ *   "packed_heavy": 1 (default) packed 12-bit-counter tables for heavy aids with fewer than 4096 runs;
+ *   "guess": 1 (default) single-pass top-k of a heavy aid's partitions from a sibling partition's threshold;
+ *   "debug_skip": timing diagnostics only (results invalid). */
 int otto_covis_set_option(otto_covis_ctx* ctx, const char* name, int64_t value);
 
 /*
