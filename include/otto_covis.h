@@ -120,7 +120,8 @@ int otto_covis_stats(otto_covis_ctx* ctx, int64_t* out /* [OTTO_COVIS_STAT_COUNT
  *   "bucket_index": 1 (default) group the runs by aid_x with LDS atomics per 1024-aid bucket, 0 one global atomic per run;
  *   "packed_heavy": 1 (default) packed 12-bit-counter tables for heavy aids with fewer than 4096 runs;
  *   "guess": 1 (default) single-pass top-k of a heavy aid's partitions from a sibling partition's threshold;
- *   "debug_skip": timing diagnostics only (results invalid). */
+ *   "debug_skip": timing diagnostics only (results invalid): 1 no gather, 2 no top-k, 4 no table clear, 8 no inserts,
+ *                 16 / 32 pair-expand without record stores / row loops. */
 int otto_covis_set_option(otto_covis_ctx* ctx, const char* name, int64_t value);
 
 /*

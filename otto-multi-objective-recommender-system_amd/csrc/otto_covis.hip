@@ -989,7 +989,7 @@ struct ReduceArgs {
     uint64_t* tau_w;               // [PK][n_aids] threshold guess of a heavy aid's partitions: a lower bound of the 32nd
     uint32_t* tau_y;               //   best key of a partition already reduced (0 = none yet); tau_y only for GROUP_TIME
     uint32_t l_cap;                // records per L partition the item lists were sized for
-    int debug_skip;                // diagnostics only (wrong results): 1 skip gather, 2 skip top-k, 4 skip table init
+    int debug_skip;                // diagnostics only (wrong results): 1 skip gather, 2 skip top-k, 4 skip table init, 8 skip inserts
 #ifdef OTTO_PHASE_PROF
     unsigned long long* prof;      // [8] summed shader-clock ticks of thread 0 per phase
 #endif
@@ -1422,6 +1422,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
 
         // one record into the table; `e` = time extra (GROUP_TIME only)
         auto insert = [&](uint32_t rc, uint32_t h, uint32_t e) {
+            if (a.debug_skip & 8) {                     // diagnostics: records are fetched but not inserted
+                if (rc == 0xDEADBEEFu && h == 1u) s_ovf = 1;
+                return;
+            }
             const uint32_t y = rc & REC_AID_MASK;
             uint32_t add0 = 0, add1 = 0, add2 = 0;
             if (GROUP == OTTO_COVIS_GROUP_TYPE) {
