@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libotto_amd.so')
+# OTTO_AMD_LIB selects another build of the SAME library (the phase-profiling build of tools/perf_covis.py --prof)
+LIB_PATH = os.environ.get('OTTO_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libotto_amd.so')
 
 MAX_FILTERS = 4
 MAX_TYPE_WEIGHTS = 4

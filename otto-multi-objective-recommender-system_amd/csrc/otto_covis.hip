@@ -2454,26 +2454,38 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
     OTTO_HIP(hipMemsetAsync(wc, 0, 4, s));
     a.work_counter = wc;
 #ifdef OTTO_PHASE_PROF
+    // diagnostic build only: per-launch phase shares (shader-clock ticks of thread 0 of every workgroup) + wall time
     static unsigned long long* d_prof = nullptr;
-    if (!d_prof) OTTO_HIP(hipMalloc(&d_prof, 96));
-    OTTO_HIP(hipMemsetAsync(d_prof, 0, 96, s));
+    static hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    if (!d_prof) { OTTO_HIP(hipMalloc(&d_prof, 96)); OTTO_HIP(hipEventCreate(&pe0)); OTTO_HIP(hipEventCreate(&pe1)); }
     a.prof = d_prof;
-    struct ProfPrint { int bin; hipStream_t s; unsigned long long* d; ~ProfPrint() {
-        unsigned long long h[12]; hipStreamSynchronize(s); hipMemcpy(h, d, 96, hipMemcpyDeviceToHost);
+    auto prof_begin = [&]() { (void)hipMemsetAsync(d_prof, 0, 96, s); (void)hipEventRecord(pe0, s); };
+    auto prof_end = [&](const char* tag, uint32_t n_work) {
+        unsigned long long h[12];
+        (void)hipEventRecord(pe1, s); (void)hipStreamSynchronize(s); (void)hipMemcpy(h, d_prof, 96, hipMemcpyDeviceToHost);
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, pe0, pe1);
         unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += h[i];
-        fprintf(stderr, "[phase-prof] bin %d:", bin);
+        fprintf(stderr, "[phase-prof] %s items %u  %.3f ms:", tag, n_work, ms);
         for (int i = 0; i < 8; ++i) fprintf(stderr, " p%d %.1f%%", i, tot ? 100.0 * h[i] / tot : 0.0);
-        fprintf(stderr, "  (ticks %llu) guess: tried %llu ok %llu toofew %llu overflow %llu\n", tot, h[8], h[9], h[10], h[11]); } } prof_print{bin, s, d_prof};
+        fprintf(stderr, "  (ticks %llu) guess: tried %llu ok %llu toofew %llu overflow %llu\n", tot, h[8], h[9], h[10], h[11]);
+    };
+#else
+    auto prof_begin = [&]() {};
+    auto prof_end = [&](const char*, uint32_t) {};
 #endif
     if (bin == 0) {
         uint32_t grid = a.n_items < 256u * 20u ? a.n_items : 256u * 20u;
         tbegin(c, OTTO_COVIS_T_REDUCE_S, s);
+        prof_begin();
         k_reduce<S_LOG2T, S_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, 5, 8><<<grid, S_THREADS, 0, s>>>(a);
+        prof_end("S", a.n_work);
         tend(c, OTTO_COVIS_T_REDUCE_S, s);
     } else if (bin == 1) {
         uint32_t grid = a.n_items < 256u * 4u ? a.n_items : 256u * 4u;
         tbegin(c, OTTO_COVIS_T_REDUCE_M, s);
+        prof_begin();
         k_reduce<M_LOG2T, M_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, (GROUP != OTTO_COVIS_GROUP_TIME ? 4 : 2), 8><<<grid, M_THREADS, 0, s>>>(a);
+        prof_end("M", a.n_work);
         tend(c, OTTO_COVIS_T_REDUCE_M, s);
     } else {
         a.pstart = nullptr;
@@ -2514,6 +2526,7 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
             am.order = c->lorder[2][mode].as<uint32_t>();
             am.n_work = (uint32_t)c->n_order[2][mode];
             OTTO_HIP(hipMemsetAsync(wc, 0, 4, s));
+            prof_begin();
             if (mode == 2) {
                 if constexpr (GROUP != OTTO_COVIS_GROUP_TIME) {
                     const uint32_t grid = am.n_work < 256u * 2u ? am.n_work : 256u * 2u;
@@ -2528,6 +2541,7 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
                 const uint32_t grid = am.n_work < 256u ? am.n_work : 256u;
                 k_reduce<L_LOG2T, L_THREADS, GROUP, false, 4, 2><<<grid, L_THREADS, 0, s>>>(am);
             }
+            prof_end(mode == 2 ? "L packed 2^13 x512" : (mode == 1 ? "L packed 2^14 x1024" : "L wide 2^13 x1024"), am.n_work);
             OTTO_HIP(hipGetLastError());
         }
         tend(c, OTTO_COVIS_T_REDUCE_L, s);

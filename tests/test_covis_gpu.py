@@ -384,74 +384,183 @@ def test_sharded_builder_two_ranks_on_one_gpu(gpu_device):
     _assert_rows_equal(merged, want, cs.ALL_KINDS)
 
 
-def test_full_otto_scale_properties(gpu_device):
-    """BASELINE.json configs[1] size (14,571,582 sessions, ~243 M events, 1,855,603 aids): too big for the
-    oracle, so parity is asserted through size-independent properties:
-      * two different code paths agree bit for bit: one feed + gap-free fast-path expand + partitioned heavy aids
-        vs  7 session chunks + general expand kernel only + the filter/re-read path for heavy aids;
-      * every list is sorted by (W desc, aid_y asc), has no duplicate aid_y, never contains aid_x, n <= k;
-      * `click_click` (symmetric mask, unit weight) is symmetric: if y is listed for x and x for y the weights match;
-      * for type-weighted kinds W is a multiple of 65536 and cart_weighted >= click_weighted-implied bounds;
-      * the pair count equals the sum of run lengths and is identical in both runs."""
+@pytest.fixture(scope='module')
+def full_otto(gpu_device):
+    """BASELINE.json configs[1] input: 14,571,582 synthetic sessions (~243 M events) over 1,855,603 aids, resident in HBM."""
     import torch
     from otto_amd.synth import generate_sessions_torch, OTTO_N_AIDS, OTTO_N_SESSIONS
-    from otto_amd.covisitation.engine import CovisBuilder
     d = generate_sessions_torch(OTTO_N_SESSIONS, n_aids=OTTO_N_AIDS, seed=42, device=gpu_device)
-    kinds = ('click_weighted', 'cart_weighted', 'click_click')
-    ts_min, ts_max = int(d['ts'].min()), int(d['ts'].max())
-    k = 20
+    d['ts_min'], d['ts_max'] = int(d['ts'].min()), int(d['ts'].max())
+    yield d
+    del d
+    torch.cuda.empty_cache()
 
-    def run(chunks, partition):
-        b = CovisBuilder(OTTO_N_AIDS, kinds=kinds, ts_min=ts_min, ts_max=ts_max, device=gpu_device)
-        b.set_option('partition', partition)
-        b.set_option('fast_path', partition)      # second run also takes the general pair-expand kernel for every window
-        S = OTTO_N_SESSIONS
-        cuts = [S * c // chunks for c in range(chunks + 1)]
-        for c in range(chunks):
-            lo, hi = cuts[c], cuts[c + 1]
-            e0, e1 = int(d['sess_off'][lo]), int(d['sess_off'][hi])
-            b.feed(d['aid'][e0:e1], d['ts'][e0:e1], d['type'][e0:e1], (d['sess_off'][lo:hi + 1] - e0).contiguous())
-        out = b.finalize(k=k)
-        st = b.stats()
-        b.close()
-        return out, st
 
-    out1, st1 = run(1, 1)
-    out2, st2 = run(7, 0)
-    assert st1['pairs'] == st2['pairs'] > 1_000_000_000 and st1['runs'] == st2['runs']
-    assert st1['items_l'] > 0 and st1['retries'] == 0
+def _full_run(d, dev, kinds, k, chunks, options):
+    from otto_amd.synth import OTTO_N_AIDS, OTTO_N_SESSIONS
+    from otto_amd.covisitation.engine import CovisBuilder
+    b = CovisBuilder(OTTO_N_AIDS, kinds=kinds, ts_min=d['ts_min'], ts_max=d['ts_max'], device=dev)
+    for name, value in options.items():
+        b.set_option(name, value)
+    S = OTTO_N_SESSIONS
+    cuts = [S * c // chunks for c in range(chunks + 1)]
+    for c in range(chunks):
+        lo, hi = cuts[c], cuts[c + 1]
+        e0, e1 = int(d['sess_off'][lo]), int(d['sess_off'][hi])
+        b.feed(d['aid'][e0:e1], d['ts'][e0:e1], d['type'][e0:e1], (d['sess_off'][lo:hi + 1] - e0).contiguous())
+    out = b.finalize(k=k)
+    st = b.stats()
+    b.close()
+    return out, st
+
+
+def _assert_outputs_identical(out1, out2, kinds, k, dev):
+    import torch
     for kind in kinds:
-        for a_, b_ in zip(out1[kind], out2[kind]):
-            nz = torch.arange(k, device=gpu_device)[None, :] < out1[kind][2][:, None]
-            if a_.dim() == 2:
-                assert torch.equal(a_[nz], b_[nz]), kind
-            else:
-                assert torch.equal(a_, b_), kind
+        n1, n2 = out1[kind][2], out2[kind][2]
+        assert torch.equal(n1, n2), f'{kind}: list lengths differ'
+        nz = torch.arange(k, device=dev)[None, :] < n1[:, None]          # entries beyond n are unspecified
+        assert torch.equal(out1[kind][0][nz], out2[kind][0][nz]), f'{kind}: aid_y differs'
+        assert torch.equal(out1[kind][1][nz], out2[kind][1][nz]), f'{kind}: W differs'
+
+
+def _assert_list_properties(out, kinds, k, dev, n_aids):
+    import torch
     for kind in kinds:
-        y, w, n = out1[kind]
-        valid = torch.arange(k, device=gpu_device)[None, :] < n[:, None]
+        y, w, n = out[kind]
+        valid = torch.arange(k, device=dev)[None, :] < n[:, None]
         assert int(n.max()) <= k and int((n > 0).sum()) > 1_000_000
         both = valid[:, 1:] & valid[:, :-1]
         w0, w1, y0, y1 = w[:, :-1], w[:, 1:], y[:, :-1], y[:, 1:]
         assert bool(((w0 > w1) | ((w0 == w1) & (y0 < y1)))[both].all()), f'{kind}: rows not sorted by (W desc, aid_y asc)'
-        xs = torch.arange(OTTO_N_AIDS, device=gpu_device, dtype=torch.int32)[:, None]
+        xs = torch.arange(n_aids, device=dev, dtype=torch.int32)[:, None]
         assert not bool(((y == xs) & valid).any()), 'aid_x listed as its own neighbour'
         assert bool((w[valid] % 65536 == 0).all()) and bool((w[valid] > 0).all())
+
+
+BENCH_KINDS = ('click_weighted', 'cart_weighted', 'order_weighted')
+
+
+def test_full_otto_bench_path_bit_exact_and_sampled_oracle(gpu_device, full_otto):
+    """The configuration ``bench.py`` times, at the size it times it (BASELINE.json configs[1]: 14,571,582 sessions,
+    ~243 M events, 1,855,603 aids, the three type-weighted kinds, top-20), through the DEFAULT options: fused register
+    pair-expand (`k_expand_fused<false>`, gap-free shortcut on), bucketed index, packed heavy-aid layouts, threshold
+    guessing. Two checks:
+
+    1. bit for bit against a run that shares none of those code paths: 7 session chunks, class-sorted pair-expand
+       kernels (`fused` 0, `fast_path` 0), global-atomic index (`bucket_index` 0), wide heavy-aid tables
+       (`packed_heavy` 0), two-pass top-k (`guess` 0);
+    2. a SAMPLED ORACLE check: ~2,000 `aid_x` stratified over the three size bins of the reduce (the five heaviest aids,
+       100 of the heaviest 3 % ~ L bin, 500 of the next 26 % ~ M bin, 1,400 of the rest ~ S bin). The row of `aid_x`
+       depends only on the sessions that hold `aid_x`, so the oracle run on exactly those sessions must reproduce the
+       rows of the sampled aids exactly (aid_y, W and n, all three kinds)."""
+    import torch
+    from otto_amd.synth import OTTO_N_AIDS, OTTO_N_SESSIONS
+    d, dev, k = full_otto, gpu_device, 20
+    out1, st1 = _full_run(d, dev, BENCH_KINDS, k, 1, {})
+    assert st1['pairs'] > 1_000_000_000 and st1['items_l'] > 0 and st1['items_m'] > 0 and st1['items_s'] > 0
+    assert st1['retries'] == 0
+    out2, st2 = _full_run(d, dev, BENCH_KINDS, k, 7, {'fused': 0, 'fast_path': 0, 'bucket_index': 0, 'packed_heavy': 0, 'guess': 0})
+    assert st1['pairs'] == st2['pairs'] and st1['runs'] == st2['runs']
+    _assert_outputs_identical(out1, out2, BENCH_KINDS, k, dev)
+    del out2
+    _assert_list_properties(out1, BENCH_KINDS, k, dev, OTTO_N_AIDS)
     # cart_weighted (1,9,6) dominates click_weighted (1,6,3) pair by pair, so its best weight per aid is >= too
-    some = out1['click_weighted'][2] > 0          # entries beyond n are unspecified
+    some = out1['click_weighted'][2] > 0
     assert bool((out1['cart_weighted'][1][:, 0] >= out1['click_weighted'][1][:, 0])[some].all())
+
+    # ---- sampled oracle ----
+    S, off, aid = OTTO_N_SESSIONS, d['sess_off'], d['aid'].long()
+    E = aid.numel()
+    L = off[1:] - off[:-1]
+    sess = torch.repeat_interleave(torch.arange(S, device=dev), L, output_size=E)
+    in_win = (off[1:][sess] - torch.arange(E, device=dev)) <= 30                     # tail window of 30 events
+    cnt = torch.bincount(aid[in_win], minlength=OTTO_N_AIDS)
+    order = torch.argsort(cnt, descending=True)
+    n_pos = int((cnt > 0).sum())
+    g = torch.Generator(device='cpu')
+    g.manual_seed(7)
+    b1, b2 = int(0.03 * n_pos), int(0.29 * n_pos)
+
+    def pick(lo, hi, m):
+        return order[lo + torch.randperm(hi - lo, generator=g)[:m].to(dev)]
+    sample = torch.unique(torch.cat((order[:5], pick(5, b1, 100), pick(b1, b2, 500), pick(b2, n_pos, 1400))))
+    marked = torch.zeros(OTTO_N_AIDS, dtype=torch.bool, device=dev)
+    marked[sample] = True
+    sel = torch.zeros(S, dtype=torch.bool, device=dev)
+    sel[sess[in_win & marked[aid]]] = True                                           # sessions whose window holds a sampled aid
+    ev_sel = sel[sess]
+    sub_off = np.r_[0, np.cumsum(L[sel].cpu().numpy())].astype(np.int64)
+    sub_aid = d['aid'][ev_sel].cpu().numpy().astype(np.uint32)
+    sub_ts, sub_typ = d['ts'][ev_sel].cpu().numpy(), d['type'][ev_sel].cpu().numpy()
+    assert 50_000 < len(sub_off) - 1 < 3_000_000, 'sample of sessions out of the intended range'
+    del sess, in_win, ev_sel, sel
+    import covis_oracle_c as coc
+    if coc.available():
+        want = coc.covis_topk_c(sub_aid, sub_ts, sub_typ, sub_off, OTTO_N_AIDS, BENCH_KINDS, k=k,
+                                ts_min=d['ts_min'], ts_max=d['ts_max'])
+    else:
+        want = co.covis_topk_numpy(sub_aid, sub_ts, sub_typ, sub_off,
+                                   co.CovisSpec(kinds=BENCH_KINDS, ts_min=d['ts_min'], ts_max=d['ts_max']), k=k)
+    smp = np.sort(sample.cpu().numpy())
+    heavy = int(cnt.max())
+    n_rows = 0
+    for kind in BENCH_KINDS:
+        wx, wy, ww = want[kind]
+        keep = np.isin(wx, smp)
+        wx, wy, ww = wx[keep], wy[keep], ww[keep]
+        y, w, n = (t[sample.sort().values].cpu().numpy() for t in out1[kind])
+        valid = np.arange(k)[None, :] < n[:, None]
+        gx = np.broadcast_to(smp[:, None], valid.shape)[valid].astype(np.uint32)
+        assert len(gx) == len(wx), f'{kind}: {len(gx)} rows for the sampled aids vs oracle {len(wx)}'
+        assert np.array_equal(gx, wx) and np.array_equal(y[valid].astype(np.uint32), wy), f'{kind}: sampled rows differ (aid)'
+        assert np.array_equal(w[valid].astype(np.uint64), ww), f'{kind}: sampled rows differ (W)'
+        n_rows += len(gx)
+    assert n_rows > 3 * 15_000 and heavy > 20_000, 'sample too thin to mean anything'
+
+
+def test_full_otto_filter_kinds_properties(gpu_device, full_otto):
+    """Same input with a filter kind configured (`click_click`, BASELINE config 1's mask): K1 then runs the class-sorted
+    M-matrix kernels and the FILTER reduce group. Checked through size-independent properties:
+      * 1 feed + partitioned heavy aids  ==  7 session chunks + the filter / re-read path for heavy aids (`partition` 0);
+      * every list sorted by (W desc, aid_y asc), no aid_x in its own list, n <= k, W a positive multiple of 65536;
+      * `click_click` (symmetric mask, unit weight) is symmetric: if y is listed for x and x for y the weights match."""
+    import torch
+    from otto_amd.synth import OTTO_N_AIDS
+    d, dev, k = full_otto, gpu_device, 20
+    kinds = ('click_weighted', 'cart_weighted', 'click_click')
+    out1, st1 = _full_run(d, dev, kinds, k, 1, {})
+    out2, st2 = _full_run(d, dev, kinds, k, 7, {'partition': 0})
+    assert st1['pairs'] == st2['pairs'] > 1_000_000_000 and st1['runs'] == st2['runs']
+    assert st1['items_l'] > 0 and st1['retries'] == 0
+    _assert_outputs_identical(out1, out2, kinds, k, dev)
+    del out2
+    _assert_list_properties(out1, kinds, k, dev, OTTO_N_AIDS)
     # symmetry of click_click on a sample of aids
     y, w, n = out1['click_click']
-    sample = torch.randperm(OTTO_N_AIDS, device=gpu_device)[:200_000]
+    sample = torch.randperm(OTTO_N_AIDS, device=dev)[:200_000]
     ys, ws, ns = y[sample].long(), w[sample], n[sample]
-    valid = torch.arange(k, device=gpu_device)[None, :] < ns[:, None]
+    valid = torch.arange(k, device=dev)[None, :] < ns[:, None]
     ys = torch.where(valid, ys, torch.zeros_like(ys))                 # entries beyond n are unspecified
     back_y, back_w, back_n = y[ys], w[ys], n[ys]                      # [m, k, k] lists of the neighbours
-    hit = (back_y == sample[:, None, None].to(torch.int32)) & (torch.arange(k, device=gpu_device)[None, None, :] < back_n[..., None])
+    hit = (back_y == sample[:, None, None].to(torch.int32)) & (torch.arange(k, device=dev)[None, None, :] < back_n[..., None])
     has = hit.any(-1) & valid
     wb = (back_w * hit).sum(-1)
     assert int(has.sum()) > 10_000, 'too few mutual pairs in the sample to test symmetry'
     assert bool((wb[has] == ws[has]).all()), 'click_click is not symmetric'
+
+
+def test_config1_click_click_100k_sessions_vs_numpy_oracle(gpu_device):
+    """BASELINE.json configs[0] at its stated size: click->click covisitation on a 100,000-session OTTO-shape sample over
+    the full aid space (1,855,603 aids), window 30, top-20 -- bit-exact against the NumPy oracle."""
+    from otto_amd.synth import OTTO_N_AIDS
+    ev = generate_sessions(100_000, n_aids=OTTO_N_AIDS, seed=42)
+    kinds = ('click_click',)
+    b, got = _build(ev, gpu_device, kinds=kinds, k=20)
+    st = {}
+    want = _oracle_rows(ev, kinds, k=20, stats=st)
+    assert b.stats()['pairs'] == st['P'] > 5_000_000
+    _assert_rows_equal(got, want, kinds)
 
 
 def test_export_all_equals_per_owner_export(gpu_device):

@@ -60,8 +60,12 @@ def test_sparse_adam_training_matches_reference_golden(gold, gpu_device, p, loss
     np.testing.assert_allclose(losses, g[p + 'step_loss'], rtol=RTOL)
     np.testing.assert_allclose(losses.reshape(ne, nb).mean(1), g[p + 'epoch_train_loss'], rtol=RTOL)
     np.testing.assert_allclose(val.reshape(ne, nb).mean(1), g[p + 'epoch_val_loss'], rtol=RTOL)
-    np.testing.assert_allclose(E1.cpu().numpy(), g[p + 'w1_T'], rtol=1e-3, atol=2e-5)
-    np.testing.assert_allclose(m1.cpu().numpy(), g[p + 'm1_T'], rtol=1e-3, atol=1e-6)
+    # final tables after 3 epochs: 1e-4 relative in norm (the stated tolerance); element-wise 1e-3 / 2e-5 because Adam's
+    # m / (sqrt(v) + eps) amplifies the fp32 summation-order noise of duplicate-row sums on near-zero gradients
+    for got, key in ((E1, 'w1_T'), (m1, 'm1_T')):
+        a = got.cpu().numpy()
+        np.testing.assert_allclose(a, g[p + key], rtol=1e-3, atol=2e-5 if key == 'w1_T' else 1e-6)
+        assert np.linalg.norm(a - g[p + key]) <= RTOL * np.linalg.norm(g[p + key])
     tgt = g[p + 'target'].reshape(-1).astype(np.float64)
     pr = preds.cpu().numpy().astype(np.float64)
     if not shared:
@@ -115,11 +119,12 @@ def test_sparse_adam_large_batch_with_heavy_duplicates_vs_oracle(gpu_device, d, 
         assert np.linalg.norm(a - ref) <= RTOL * np.linalg.norm(ref)
 
 
-def test_bpr_negatives_and_batch_step_vs_oracle(gpu_device):
+@pytest.mark.parametrize('d', [64, 128])       # 64: BASELINE config 3; 128: config 5
+def test_bpr_negatives_and_batch_step_vs_oracle(gpu_device, d):
     import torch
     from otto_amd.matrix_factorization.engine import MFEngine, BPR_BATCH
     rng = np.random.default_rng(9)
-    nu, ni, d, B = 5000, 400, 64, 3000
+    nu, ni, B = 5000, 400, 3000
     U = (rng.standard_normal((nu, d)) * 0.2).astype(np.float32)
     V = (rng.standard_normal((ni, d)) * 0.2).astype(np.float32)
     u = rng.integers(0, nu, B)
@@ -138,11 +143,12 @@ def test_bpr_negatives_and_batch_step_vs_oracle(gpu_device):
         np.testing.assert_allclose(dV.cpu().numpy(), V, rtol=RTOL, atol=1e-6)
 
 
-def test_bpr_hogwild_equals_oracle_on_race_free_batch_and_learns(gpu_device):
+@pytest.mark.parametrize('d', [32, 128])
+def test_bpr_hogwild_equals_oracle_on_race_free_batch_and_learns(gpu_device, d):
     import torch
     from otto_amd.matrix_factorization.engine import MFEngine, BPR_HOGWILD
     rng = np.random.default_rng(10)
-    nu, ni, d, B = 4096, 100000, 32, 2048
+    nu, ni, B = 4096, 100000, 2048
     U = (rng.standard_normal((nu, d)) * 0.2).astype(np.float32)
     V = (rng.standard_normal((ni, d)) * 0.2).astype(np.float32)
     u = rng.permutation(nu)[:B]
@@ -189,6 +195,41 @@ def test_score_topk_matches_oracle(gpu_device, B, N, d, k, pad):
         assert np.allclose(S[rows, got[diff]], S[rows, wi[diff]], rtol=RTOL, atol=1e-5)
     if pad >= 0:
         assert (got != pad).all()
+
+
+def test_bpr_d128_recall_at_20_matches_cpu_path(gpu_device):
+    """BASELINE config 5's acceptance check on one GPU: BPR hogwild training at d = 128 on a planted-structure
+    dataset, then recall@20 (src/metrics.py:4-28 semantics, restated in oracle/mf_oracle.py) of the HIP full-sort top-20
+    against the same metric computed from the CPU oracle's top-20 of the SAME trained tables. The two top-20 lists may
+    differ only where fp32 scores tie within rounding, so the recalls agree within 1e-4 relative (north-star tolerance)."""
+    import torch
+    from otto_amd.matrix_factorization.bpr import BPR, train_epoch
+    rng = np.random.default_rng(0)
+    n_users, n_items, groups, d = 3000, 1501, 15, 128
+    grp = rng.integers(0, groups, n_users)
+    item_grp = np.r_[-1, rng.integers(0, groups, n_items - 1)]     # item 0 = PAD
+    by = [np.flatnonzero(item_grp == g_) for g_ in range(groups)]
+    u = np.repeat(np.arange(n_users), 12)
+    i = np.array([rng.choice(by[grp[x]]) for x in u])
+    held = np.array([rng.choice(by[grp[x]]) for x in range(n_users)])
+    torch.manual_seed(0)
+    model = BPR(n_users, n_items, d)
+    with torch.no_grad():
+        model.user_embedding.weight.normal_(0, 0.1)
+        model.item_embedding.weight.normal_(0, 0.1)
+    model.to(gpu_device)
+    du, di = torch.from_numpy(u).to(gpu_device), torch.from_numpy(i).to(gpu_device)
+    losses = [train_epoch(model, du, di, lr=0.1, seed=1, epoch=e, rows_per_launch=8192) for e in range(30)]
+    assert losses[-1] < 0.5 * losses[0]
+    ids, _ = model.full_sort_topk(torch.arange(n_users, device=gpu_device), k=20, pad_col=0)
+    ids = ids.cpu().numpy()
+    U, V = model.user_embedding.weight.detach().cpu().numpy(), model.item_embedding.weight.detach().cpu().numpy()
+    wi, _ = mo.score_topk(U, V, k=20, pad_col=0)
+    r_gpu = np.mean([mo.click_recall([h], row.tolist()) for h, row in zip(held, ids)])
+    r_cpu = np.mean([mo.click_recall([h], row.tolist()) for h, row in zip(held, wi)])
+    assert r_cpu > 0.1, 'training did not learn the planted structure'
+    assert abs(r_gpu - r_cpu) <= RTOL * r_cpu, (r_gpu, r_cpu)
+    assert (ids == wi).mean() > 0.99
 
 
 def test_score_topk_exact_ties_prefer_smaller_id(gpu_device):

@@ -1,6 +1,9 @@
 """Exploratory timing of the covisitation pipeline on one GPU (not the bench contract)."""
 import argparse, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if '--prof' in sys.argv:      # phase-profiling build (make -C csrc prof): per-launch phase shares on stderr
+    os.environ['OTTO_AMD_LIB'] = os.path.join(ROOT, 'otto-multi-objective-recommender-system_amd', 'csrc', 'libotto_amd_prof.so')
 import torch
 from otto_amd.synth import generate_sessions_torch, OTTO_N_AIDS
 from otto_amd.covisitation.engine import CovisBuilder
@@ -13,6 +16,9 @@ ap.add_argument('--l-cap', type=int, default=0)
 ap.add_argument('--k', type=int, default=20)
 ap.add_argument('--skip', type=int, default=0)
 ap.add_argument('--partition', type=int, default=1)
+ap.add_argument('--prof', action='store_true')
+ap.add_argument('--opt', action='append', default=[], help='name=value for otto_covis_set_option (repeatable)')
+ap.add_argument('--export', action='store_true', help='also time the multi-GPU export / import ends')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 t = time.time()
@@ -26,6 +32,9 @@ if a.l_cap:
 if a.skip:
     b.set_option('debug_skip', a.skip)
 b.set_option('partition', a.partition)
+for o in a.opt:
+    name, value = o.split('=')
+    b.set_option(name, int(value))
 for r in range(a.reps):
     b.reset()
     torch.cuda.synchronize(); t0 = time.time()
@@ -40,6 +49,8 @@ for r in range(a.reps):
     print('   timings(ms)', {k: round(v, 3) for k, v in tm.items()}, flush=True)
 print('mem GB', torch.cuda.max_memory_allocated()/1e9)
 
+if not a.export:
+    sys.exit(0)
 # export/import cost of the multi-GPU exchange for 8 owners (single-GPU measurement; RCCL time not included)
 import time as _t
 from otto_amd.covisitation.distributed import owner_bounds
