@@ -47,6 +47,22 @@ int otto_mf_forward(otto_mf_ctx* ctx, const float* d_E1, const float* d_E2, cons
 int otto_mf_eval(otto_mf_ctx* ctx, const float* d_E1, const float* d_E2, const int64_t* d_i1, const int64_t* d_i2,
                  const int64_t* d_target, int64_t B, int32_t loss_kind, float* d_pred, float* d_loss_out, void* stream);
 
+/* validate() with scores (torch_trainer.py:126-161 + matrix_factorization/metrics.py:30-85) without copying the
+ * predictions to the host: as otto_mf_eval, and the context's running sums grow by this batch's
+ *   sum |p - t|, sum (p - t)^2, #{(p >= 0.5) == (t >= 0.5)}, B      (double precision, added in launch order)
+ * with p = the raw output for OTTO_MF_LOSS_MSE models and sigmoid(output) for OTTO_MF_LOSS_BCE models: mean absolute error,
+ * mean squared error and accuracy at the reference's threshold 0.5 are quotients of these sums. */
+int otto_mf_eval_sums(otto_mf_ctx* ctx, const float* d_E1, const float* d_E2, const int64_t* d_i1, const int64_t* d_i2,
+                      const int64_t* d_target, int64_t B, int32_t loss_kind, float* d_pred, float* d_loss_out, void* stream);
+/* h_sums[4] (host) = the running sums above; reset != 0 clears them afterwards. Synchronises the stream. */
+int otto_mf_read_sums(otto_mf_ctx* ctx, double* h_sums, int32_t reset, void* stream);
+
+/* Row ids are range-checked in every kernel: a sample whose id falls outside its table is skipped (its prediction is NaN)
+ * and counted. otto_mf_check synchronises the stream and returns 0 if no sample was skipped since the last call, else -22
+ * (EINVAL) with the count in *n_bad (nullable) and the message in otto_last_error(); the counter is cleared. The reference
+ * would raise an IndexError from nn.Embedding (torch_modules.py:15-16, 34-35) at the offending batch. */
+int otto_mf_check(otto_mf_ctx* ctx, int64_t* n_bad, void* stream);
+
 /* One optimizer step. (d_m*, d_v*) = SparseAdam exp_avg / exp_avg_sq, same shape as the table.
  * t = 1-based global step count AFTER this step (torch's state['step']). shared_table contexts
  * pass the same pointers for table 2.  *d_loss_out = mean loss of the batch before the update. */

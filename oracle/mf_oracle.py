@@ -63,9 +63,11 @@ def _adam_rows(E, m, v, touched, g, lr, betas, eps, step):
 
 
 def sparse_adam_step(E1, m1, v1, E2, m2, v2, i1, i2, target, kind, lr, betas=(0.9, 0.999), eps=1e-8, step=1,
-                     shared=False):
-    """One train() batch (torch_trainer.py:59-78). Tables updated in place; returns (mean loss, pred)."""
-    B = len(i1)
+                     shared=False, batch_size=None):
+    """One train() batch (torch_trainer.py:59-78). Tables updated in place; returns (mean loss, pred).
+    ``batch_size``: divisor of reduction='mean' when it differs from len(i1) (a batch some of whose samples were
+    skipped by the device kernels' range check)."""
+    B = len(i1) if batch_size is None else int(batch_size)
     out = forward(E1, E2, i1, i2)
     l, g = loss_and_grad(kind, out, target)
     c = (g / B)[:, None]

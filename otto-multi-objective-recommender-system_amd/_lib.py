@@ -95,6 +95,9 @@ SIGNATURES = {
     'otto_mf_destroy': (None, [_vp]),
     'otto_mf_forward': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'otto_mf_eval': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    'otto_mf_eval_sums': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    'otto_mf_read_sums': (_i32, [_vp, C.POINTER(C.c_double), _i32, _vp]),
+    'otto_mf_check': (_i32, [_vp, _p_i64, _vp]),
     'otto_mf_step_sparse_adam': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32,
                                         C.c_double, C.c_double, C.c_double, C.c_double, _i64, _vp, _vp]),
     'otto_mf_bpr_step': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, C.c_uint64, C.c_uint64, _i64, C.c_float, C.c_float,

@@ -1080,9 +1080,11 @@ __device__ __forceinline__ void wave_topk_select_multi(K (&c)[NK][MPL], int nk, 
 // (wave w owns runs r0 + w, r0 + w + NW, ...): a wave fetches 64 of its run descriptors with one load, then
 // walks them two at a time (one per 32-lane half) with GATHER_U record loads in flight per lane, so an item
 // of a few dozen runs costs two or three dependent memory round trips instead of one per run.
-template <int NW, int GATHER_U, typename F>
-__device__ __forceinline__ void for_each_record(const uint64_t* sorted_desc, const uint32_t* rec, uint64_t r0, uint64_t r1,
-                                                int wid, F f) {
+// fb(rc, slot, ok) receives GATHER_U records at a time (arrays; ok[u] = lane holds a record), so that the consumer can
+// put GATHER_U independent LDS operations in flight before it looks at any result.
+template <int NW, int GATHER_U, typename FB>
+__device__ __forceinline__ void for_each_record_batch(const uint64_t* sorted_desc, const uint32_t* rec, uint64_t r0, uint64_t r1,
+                                                      int wid, FB fb) {
     const unsigned lane = lane_id();
     const uint32_t l = lane & 31u;
     const int half = (int)(lane >> 5);
@@ -1110,11 +1112,7 @@ __device__ __forceinline__ void for_each_record(const uint64_t* sorted_desc, con
                 rc[u] = ok[u] ? rec[sl[u]] : 0u;
             }
         };
-        auto consume = [&](uint32_t (&rc)[GATHER_U], uint64_t (&sl)[GATHER_U], bool (&ok)[GATHER_U]) {
-#pragma unroll
-            for (int u = 0; u < GATHER_U; ++u)
-                if (ok[u]) f(rc[u], sl[u]);
-        };
+        auto consume = [&](uint32_t (&rc)[GATHER_U], uint64_t (&sl)[GATHER_U], bool (&ok)[GATHER_U]) { fb(rc, sl, ok); };
         // two batches of 2*GATHER_U runs alternate: the loads of one are in flight while the other is consumed
         if (nrun > 0) issue(0, rcA, slA, okA);
         for (int t = 0; t < nrun; t += 4 * GATHER_U) {
@@ -1126,6 +1124,17 @@ __device__ __forceinline__ void for_each_record(const uint64_t* sorted_desc, con
         }
         d = dn;
     }
+}
+
+template <int NW, int GATHER_U, typename F>
+__device__ __forceinline__ void for_each_record(const uint64_t* sorted_desc, const uint32_t* rec, uint64_t r0, uint64_t r1,
+                                                int wid, F f) {
+    for_each_record_batch<NW, GATHER_U>(sorted_desc, rec, r0, r1, wid,
+                                        [&](uint32_t (&rc)[GATHER_U], uint64_t (&sl)[GATHER_U], bool (&ok)[GATHER_U]) {
+#pragma unroll
+        for (int u = 0; u < GATHER_U; ++u)
+            if (ok[u]) f(rc[u], sl[u]);
+    });
 }
 
 __device__ __forceinline__ uint32_t rec_hash(uint32_t rc) { return (rc & REC_AID_MASK) * 0x9E3779B1u; }
@@ -1286,7 +1295,8 @@ struct ItemDesc {      // everything a workgroup needs about its item, fetched o
 #else
 #define OTTO_PH(i) do {} while (0)
 #endif
-template <int LOG2T, int THREADS, int GROUP, bool PACKED, int MINW, int GU>
+// DBG: the timing diagnostics of `debug_skip` (wrong results) are compiled into a second instantiation only
+template <int LOG2T, int THREADS, int GROUP, bool PACKED, int MINW, int GU, bool DBG>
 __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     constexpr int T = 1 << LOG2T;
     constexpr int NW = THREADS / 64;
@@ -1406,7 +1416,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 kload(guess[j], a.tau_w[o], WIDE ? a.tau_y[o] : 0u);
             }
         }
-        if (!(a.debug_skip & 4)) {
+        if (!(DBG && (a.debug_skip & 4))) {
             for (int i = threadIdx.x; i < T; i += THREADS) {
                 if (PACKED) {
                     s_tab[i] = TAB_EMPTY;
@@ -1420,59 +1430,101 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         __syncthreads();
         OTTO_PH(1);
 
-        // one record into the table; `e` = time extra (GROUP_TIME only)
-        auto insert = [&](uint32_t rc, uint32_t h, uint32_t e) {
-            if (a.debug_skip & 8) {                     // diagnostics: records are fetched but not inserted
-                if (rc == 0xDEADBEEFu && h == 1u) s_ovf = 1;
-                return;
-            }
-            const uint32_t y = rc & REC_AID_MASK;
-            uint32_t add0 = 0, add1 = 0, add2 = 0;
-            if (GROUP == OTTO_COVIS_GROUP_TYPE) {
-                const uint32_t tyj = (rc >> REC_AID_BITS) & 3u;
-                add0 = tyj == 0; add1 = tyj == 1; add2 = tyj == 2;
-            } else if (GROUP == OTTO_COVIS_GROUP_FILTER) {
-                const uint32_t fb = (rc >> 28) >> a.chan_shift;
-                add0 = fb & 1u; add1 = (fb >> 1) & 1u; add2 = (fb >> 2) & 1u;
-                if (!(add0 | add1 | add2)) return;
-            }
-            uint32_t slot = h >> (32 - LOG2T);
-            if (PACKED) {
-                const unsigned long long add = (unsigned long long)add0 | ((unsigned long long)add1 << 12) |
-                                               ((unsigned long long)add2 << 24);
-                const unsigned long long fresh = (unsigned long long)y << 36;
-                // CAS first, no read: a new key (most records of these bins) costs ONE LDS operation -- it goes in
-                // together with its first count; a key already there costs the failed CAS + one add
-                for (int probe = 0; probe < T; ++probe) {
-                    const unsigned long long old = atomicCAS((unsigned long long*)&s_tab[slot], (unsigned long long)TAB_EMPTY, fresh | add);
-                    if (old == TAB_EMPTY) return;
-                    if ((uint32_t)(old >> 36) == y) {
-                        atomicAdd((unsigned long long*)&s_tab[slot], add);
-                        return;
-                    }
-                    slot = (slot + 1) & (T - 1);
-                }
-                s_ovf = 1;
-                return;
-            }
-            int found = -1;
-            for (int probe = 0; probe < T; ++probe) {            // CAS first, no read (see the packed layout)
-                const uint32_t old = atomicCAS(&s_key[slot], KEY_EMPTY, y);
-                if (old == KEY_EMPTY || old == y) { found = (int)slot; break; }
+        // Records go into the table N at a time: the first-probe CAS of all N is issued back to back (N independent LDS
+        // round trips in flight per lane instead of one), then hits (key already there: add) and misses (next probe) are
+        // resolved. `e` = time extra (GROUP_TIME only). CAS first, no read: a new key (most records) costs ONE LDS
+        // operation in the packed layout -- it goes in together with its first count.
+        auto probe_on = [&](uint32_t y, uint32_t slot, unsigned long long add, unsigned long long fresh) {   // packed: slots after the first
+            for (int probe = 1; probe < T; ++probe) {
                 slot = (slot + 1) & (T - 1);
+                const unsigned long long old = atomicCAS((unsigned long long*)&s_tab[PACKED ? slot : 0], (unsigned long long)TAB_EMPTY, fresh | add);
+                if (old == TAB_EMPTY) return;
+                if ((uint32_t)(old >> 36) == y) {
+                    atomicAdd((unsigned long long*)&s_tab[PACKED ? slot : 0], add);
+                    return;
+                }
             }
-            if (found < 0) { s_ovf = 1; return; }
+            s_ovf = 1;
+        };
+        auto wide_add = [&](uint32_t rc, uint32_t found, uint32_t e) {
             if (GROUP == OTTO_COVIS_GROUP_TIME) {
-                atomicAdd(&s_v[0][found], 1u);
-                const uint32_t old = atomicAdd(&s_v[1][found], e);
-                if (old + e < old) atomicAdd(&s_v[2][found], 1u);
+                atomicAdd(&s_v[0][PACKED ? 0 : found], 1u);
+                const uint32_t old = atomicAdd(&s_v[1][PACKED ? 0 : found], e);
+                if (old + e < old) atomicAdd(&s_v[2][PACKED ? 0 : found], 1u);
             } else if (GROUP == OTTO_COVIS_GROUP_TYPE) {
                 const uint32_t tyj = (rc >> REC_AID_BITS) & 3u;            // exactly one counter: one LDS atomic, no divergence
-                if (tyj < 3u) atomicAdd(&s_v[tyj][found], 1u);
+                if (tyj < 3u) atomicAdd(&s_v[tyj][PACKED ? 0 : found], 1u);
             } else {
-                if (add0) atomicAdd(&s_v[0][found], 1u);
-                if (add1) atomicAdd(&s_v[1][found], 1u);
-                if (add2) atomicAdd(&s_v[2][found], 1u);
+                const uint32_t fb = (rc >> 28) >> a.chan_shift;
+                if (fb & 1u) atomicAdd(&s_v[0][PACKED ? 0 : found], 1u);
+                if (fb & 2u) atomicAdd(&s_v[1][PACKED ? 0 : found], 1u);
+                if (fb & 4u) atomicAdd(&s_v[2][PACKED ? 0 : found], 1u);
+            }
+        };
+        auto insert_batch = [&](auto ntag, const uint32_t* rc, const bool* okin, const uint32_t* e) {
+            constexpr int N = decltype(ntag)::value;
+            if (DBG && (a.debug_skip & 8)) {                 // diagnostics: records are fetched but not inserted
+#pragma unroll
+                for (int u = 0; u < N; ++u)
+                    if (okin[u] && rc[u] == 0xDEADBEEFu) s_ovf = 1;
+                return;
+            }
+            bool ok[N];
+            uint32_t slot[N];
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                ok[u] = okin[u];
+                if (GROUP == OTTO_COVIS_GROUP_FILTER && (((rc[u] >> 28) >> a.chan_shift) & 7u) == 0u) ok[u] = false;
+                slot[u] = rec_hash(rc[u]) >> (32 - LOG2T);
+            }
+            if (PACKED) {
+                unsigned long long add[N], old[N];
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    uint32_t add0, add1, add2;
+                    if (GROUP == OTTO_COVIS_GROUP_TYPE) {
+                        const uint32_t tyj = (rc[u] >> REC_AID_BITS) & 3u;
+                        add0 = tyj == 0; add1 = tyj == 1; add2 = tyj == 2;
+                    } else {
+                        const uint32_t fb = (rc[u] >> 28) >> a.chan_shift;
+                        add0 = fb & 1u; add1 = (fb >> 1) & 1u; add2 = (fb >> 2) & 1u;
+                    }
+                    add[u] = (unsigned long long)add0 | ((unsigned long long)add1 << 12) | ((unsigned long long)add2 << 24);
+                    old[u] = TAB_EMPTY;
+                    if (ok[u])
+                        old[u] = atomicCAS((unsigned long long*)&s_tab[PACKED ? slot[u] : 0], (unsigned long long)TAB_EMPTY,
+                                           ((unsigned long long)(rc[u] & REC_AID_MASK) << 36) | add[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    if (old[u] == TAB_EMPTY) continue;        // not a record, or a new key that went in with its first count
+                    const uint32_t y = rc[u] & REC_AID_MASK;
+                    if ((uint32_t)(old[u] >> 36) == y) atomicAdd((unsigned long long*)&s_tab[PACKED ? slot[u] : 0], add[u]);
+                    else probe_on(y, slot[u], add[u], (unsigned long long)y << 36);
+                }
+                return;
+            }
+            uint32_t old[N];
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                old[u] = KEY_EMPTY;
+                if (ok[u]) old[u] = atomicCAS(&s_key[PACKED ? 0 : slot[u]], KEY_EMPTY, rc[u] & REC_AID_MASK);
+            }
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                if (!ok[u]) continue;
+                const uint32_t y = rc[u] & REC_AID_MASK;
+                int found = (old[u] == KEY_EMPTY || old[u] == y) ? (int)slot[u] : -1;
+                if (found < 0) {
+                    uint32_t sl = slot[u];
+                    for (int probe = 1; probe < T; ++probe) {
+                        sl = (sl + 1) & (T - 1);
+                        const uint32_t o2 = atomicCAS(&s_key[PACKED ? 0 : sl], KEY_EMPTY, y);
+                        if (o2 == KEY_EMPTY || o2 == y) { found = (int)sl; break; }
+                    }
+                }
+                if (found < 0) { s_ovf = 1; continue; }
+                wide_add(rc[u], (uint32_t)found, e[u]);
             }
         };
 
@@ -1511,7 +1563,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 kstore(best, &a.part_w[o], &a.part_y[o]);
             }
         };
-        if (a.debug_skip & 1) {
+        if (DBG && (a.debug_skip & 1)) {
         } else if (lgR > 0 && a.pstart) {
             // heavy aid, records already bucketed by hash partition: contiguous coalesced reads
             const uint64_t ps = cur.ps, pe = cur.pe;
@@ -1525,16 +1577,23 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                     rc[u] = i < pe ? a.prec[i] : KEY_EMPTY;
                     e[u] = (GROUP == OTTO_COVIS_GROUP_TIME && i < pe) ? a.ptw[i] : 0u;
                 }
+                bool okb[BU];
 #pragma unroll
-                for (int u = 0; u < BU; ++u)
-                    if (rc[u] != KEY_EMPTY) insert(rc[u], rec_hash(rc[u]), e[u]);
+                for (int u = 0; u < BU; ++u) okb[u] = rc[u] != KEY_EMPTY;
+                insert_batch(std::integral_constant<int, BU>{}, rc, okb, e);
                 if (s_ovf) break;
             }
         } else {
-            for_each_record<NW, GU>(a.sorted_desc, a.rec, cur.rb, cur.re, wid, [&](uint32_t rc, uint64_t slot) {
-                const uint32_t h = rec_hash(rc);
-                if (lgR == 0 || ((h >> pshift) & pmask) == part)
-                    insert(rc, h, GROUP == OTTO_COVIS_GROUP_TIME ? a.tw[slot] : 0u);
+            for_each_record_batch<NW, GU>(a.sorted_desc, a.rec, cur.rb, cur.re, wid,
+                                          [&](uint32_t (&rc)[GU], uint64_t (&sl)[GU], bool (&ok)[GU]) {
+                uint32_t e[GU];
+                bool okb[GU];
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    okb[u] = ok[u] && (lgR == 0 || ((rec_hash(rc[u]) >> pshift) & pmask) == part);
+                    e[u] = (GROUP == OTTO_COVIS_GROUP_TIME && okb[u]) ? a.tw[sl[u]] : 0u;
+                }
+                insert_batch(std::integral_constant<int, GU>{}, rc, okb, e);
             });
         }
         // stage 2 of the next item (its item word has long arrived)
@@ -1544,7 +1603,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         OTTO_PH(3);
         const bool ovf = s_ovf != 0;
         bool fast_done = false;
-        if (NW > 1 && use_guess && !ovf && !(a.debug_skip & 2)) {
+        if (NW > 1 && use_guess && !ovf && !(DBG && (a.debug_skip & 2))) {
             constexpr int MPLG = T / THREADS;
             bool gv = true;
 #pragma unroll
@@ -1593,7 +1652,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             }
         }
         OTTO_PH(7);
-        if (fast_done || (a.debug_skip & 2)) {
+        if (fast_done || (DBG && (a.debug_skip & 2))) {
         } else if (ovf) {
             // LDS table full: ask the host to redo this aid with twice the partitions
             if (threadIdx.x == 0) {
@@ -2442,6 +2501,15 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
     return 0;
 }
 
+// the diagnostics instantiation (DBG) exists for the TYPE group only (the bench path); debug_skip is ignored elsewhere
+#define OTTO_LAUNCH_REDUCE(grid, threads, args, ...)                                                   \
+    do {                                                                                               \
+        if (GROUP == OTTO_COVIS_GROUP_TYPE && (args).debug_skip)                                       \
+            k_reduce<__VA_ARGS__, GROUP == OTTO_COVIS_GROUP_TYPE><<<grid, threads, 0, s>>>(args);      \
+        else                                                                                           \
+            k_reduce<__VA_ARGS__, false><<<grid, threads, 0, s>>>(args);                               \
+    } while (0)
+
 template <int GROUP>
 static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s) {
     a.items = c->items[bin].as<uint64_t>();
@@ -2477,14 +2545,14 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
         uint32_t grid = a.n_items < 256u * 20u ? a.n_items : 256u * 20u;
         tbegin(c, OTTO_COVIS_T_REDUCE_S, s);
         prof_begin();
-        k_reduce<S_LOG2T, S_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, 5, 8><<<grid, S_THREADS, 0, s>>>(a);
+        OTTO_LAUNCH_REDUCE(grid, S_THREADS, a, S_LOG2T, S_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, 5, 8);
         prof_end("S", a.n_work);
         tend(c, OTTO_COVIS_T_REDUCE_S, s);
     } else if (bin == 1) {
         uint32_t grid = a.n_items < 256u * 4u ? a.n_items : 256u * 4u;
         tbegin(c, OTTO_COVIS_T_REDUCE_M, s);
         prof_begin();
-        k_reduce<M_LOG2T, M_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, (GROUP != OTTO_COVIS_GROUP_TIME ? 4 : 2), 8><<<grid, M_THREADS, 0, s>>>(a);
+        OTTO_LAUNCH_REDUCE(grid, M_THREADS, a, M_LOG2T, M_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, (GROUP != OTTO_COVIS_GROUP_TIME ? 4 : 2), 8);
         prof_end("M", a.n_work);
         tend(c, OTTO_COVIS_T_REDUCE_M, s);
     } else {
@@ -2530,16 +2598,16 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
             if (mode == 2) {
                 if constexpr (GROUP != OTTO_COVIS_GROUP_TIME) {
                     const uint32_t grid = am.n_work < 256u * 2u ? am.n_work : 256u * 2u;
-                    k_reduce<L_LOG2T, 512, GROUP, true, 4, 4><<<grid, 512, 0, s>>>(am);
+                    OTTO_LAUNCH_REDUCE(grid, 512, am, L_LOG2T, 512, GROUP, true, 4, 4);
                 }
             } else if (mode == 1) {
                 if constexpr (GROUP != OTTO_COVIS_GROUP_TIME) {
                     const uint32_t grid = am.n_work < 256u ? am.n_work : 256u;
-                    k_reduce<LP_LOG2T, L_THREADS, GROUP, true, 4, 2><<<grid, L_THREADS, 0, s>>>(am);
+                    OTTO_LAUNCH_REDUCE(grid, L_THREADS, am, LP_LOG2T, L_THREADS, GROUP, true, 4, 2);
                 }
             } else {
                 const uint32_t grid = am.n_work < 256u ? am.n_work : 256u;
-                k_reduce<L_LOG2T, L_THREADS, GROUP, false, 4, 2><<<grid, L_THREADS, 0, s>>>(am);
+                OTTO_LAUNCH_REDUCE(grid, L_THREADS, am, L_LOG2T, L_THREADS, GROUP, false, 4, 2);
             }
             prof_end(mode == 2 ? "L packed 2^13 x512" : (mode == 1 ? "L packed 2^14 x1024" : "L wide 2^13 x1024"), am.n_work);
             OTTO_HIP(hipGetLastError());

@@ -61,20 +61,35 @@ __device__ __forceinline__ void block_loss_partial(float v, float* partial) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_loss_final(const float* partial, int n, float scale, float* out) {
+// out = sum of partial[0..n) * scale; sums (nullable): sums[q] += sum of partial[(q + 1) * stride ..) in double -- the
+// running score sums of validate() (one launch per batch on one stream: the additions are ordered, no atomics)
+__global__ __launch_bounds__(256) void k_loss_final(const float* partial, int n, float scale, float* out, double* sums,
+                                                    int n_sums, int stride, double count) {
     __shared__ float s_w[4];
-    float v = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (lane_id() == 0) s_w[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) *out = (s_w[0] + s_w[1] + s_w[2] + s_w[3]) * scale;
+    for (int q = 0; q <= n_sums; ++q) {
+        float v = 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) v += partial[q * stride + i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if (lane_id() == 0) s_w[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float t = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+            if (q == 0) *out = t * scale;
+            else sums[q - 1] += (double)t;
+        }
+    }
+    if (threadIdx.x == 0 && sums) sums[n_sums] += count;
 }
 
 // ---------------------------------------------------------------------------
 // forward / eval / step phase 1
-//   MODE 0: pred only; 1: pred (optional) + loss partials; 2: + coef + owner claims (training)
+//   MODE 0: pred only; 1: pred (optional) + loss partials; 3: + score partials of validate() (|e|, e^2, hits)
+// Samples whose row ids fall outside the tables are skipped (pred = NaN) and counted in *err: the caller sees
+// OTTO_EINVAL from otto_mf_check instead of a memory fault.
 // ---------------------------------------------------------------------------
+constexpr int MF_GRID_MAX = 256 * 8;
+
 struct FwdArgs {
     const float* E1;
     const float* E2;
@@ -82,14 +97,13 @@ struct FwdArgs {
     const int64_t* i2;
     const int64_t* target;
     int64_t B;
+    int64_t n1, n2;
     int d;
     int G;          // lanes per sample = d / 4
     int loss_kind;
     float* pred;    // nullable
-    float* partial; // [gridDim.x]
-    float* coef;    // [B] dL/dout / B
-    int32_t* owner1;
-    int32_t* owner2;
+    float* partial; // [4][MF_GRID_MAX]
+    uint32_t* err;
 };
 
 template <int MODE>
@@ -99,10 +113,16 @@ __global__ __launch_bounds__(256) void k_mf_fwd(FwdArgs a) {
     const int64_t groups_per_block = 256 / G;
     const int64_t g0 = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / G;
     const int64_t gstride = (int64_t)gridDim.x * groups_per_block;
-    float lsum = 0.f;
-    const float invB = 1.0f / (float)a.B;
+    float lsum = 0.f, s_abs = 0.f, s_sq = 0.f, s_hit = 0.f;
     for (int64_t b = g0; b < a.B; b += gstride) {
         const int64_t r1 = a.i1[b], r2 = a.i2[b];
+        if ((uint64_t)r1 >= (uint64_t)a.n1 || (uint64_t)r2 >= (uint64_t)a.n2) {
+            if (gl == 0) {
+                atomicAdd(a.err, 1u);
+                if (a.pred) a.pred[b] = __builtin_nanf("");
+            }
+            continue;
+        }
         const float4 e1 = ld4(a.E1 + r1 * a.d + 4 * gl);
         const float4 e2 = ld4(a.E2 + r2 * a.d + 4 * gl);
         const float out = group_sum(dot4(e1, e2), G);
@@ -110,62 +130,65 @@ __global__ __launch_bounds__(256) void k_mf_fwd(FwdArgs a) {
             if (a.pred) a.pred[b] = out;
             if (MODE >= 1) {
                 float l, g;
-                loss_grad(a.loss_kind, out, (float)a.target[b], &l, &g);
+                const float t = (float)a.target[b];
+                loss_grad(a.loss_kind, out, t, &l, &g);
                 lsum += l;
-                if (MODE == 2) {
-                    a.coef[b] = g * invB;
-                    atomicMin(&a.owner1[r1], (int32_t)b);
-                    atomicMin(&a.owner2[r2], (int32_t)(a.B + b));
+                if (MODE == 3) {
+                    // what validate() scores: the raw output (MSE models) or sigmoid(output) (BCE models) against the target;
+                    // hit = (probability >= 0.5) == label, i.e. accuracy at the reference's threshold 0.5
+                    const float p = a.loss_kind == OTTO_MF_LOSS_MSE ? out : 1.0f / (1.0f + expf(-out));
+                    const float e = p - t;
+                    s_abs += fabsf(e);
+                    s_sq += e * e;
+                    s_hit += ((p >= 0.5f) == (t >= 0.5f)) ? 1.0f : 0.0f;
                 }
             }
         }
     }
     if (MODE >= 1) block_loss_partial<256>(lsum, a.partial);
-}
-
-// phase 2: every occurrence adds its gradient row into its row owner's slot
-struct AccArgs {
-    const float* E1;
-    const float* E2;
-    const int64_t* i1;
-    const int64_t* i2;
-    const float* coef;
-    const int32_t* owner1;
-    const int32_t* owner2;
-    float* grad;   // [2B, d]
-    int64_t B;
-    int d;
-    int G;
-};
-
-__global__ __launch_bounds__(256) void k_mf_acc(AccArgs a) {
-    const int G = a.G;
-    const int gl = threadIdx.x & (G - 1);
-    const int64_t gpb = 256 / G;
-    for (int64_t b = (int64_t)blockIdx.x * gpb + threadIdx.x / G; b < a.B; b += (int64_t)gridDim.x * gpb) {
-        const int64_t r1 = a.i1[b], r2 = a.i2[b];
-        const float c = a.coef[b];
-        const float4 e1 = ld4(a.E1 + r1 * a.d + 4 * gl);
-        const float4 e2 = ld4(a.E2 + r2 * a.d + 4 * gl);
-        float* g1 = a.grad + (int64_t)a.owner1[r1] * a.d + 4 * gl;
-        float* g2 = a.grad + (int64_t)a.owner2[r2] * a.d + 4 * gl;
-        atomicAdd(g1 + 0, c * e2.x); atomicAdd(g1 + 1, c * e2.y); atomicAdd(g1 + 2, c * e2.z); atomicAdd(g1 + 3, c * e2.w);
-        atomicAdd(g2 + 0, c * e1.x); atomicAdd(g2 + 1, c * e1.y); atomicAdd(g2 + 2, c * e1.z); atomicAdd(g2 + 3, c * e1.w);
+    if (MODE == 3) {
+        __syncthreads();
+        block_loss_partial<256>(s_abs, a.partial + MF_GRID_MAX);
+        __syncthreads();
+        block_loss_partial<256>(s_sq, a.partial + 2 * MF_GRID_MAX);
+        __syncthreads();
+        block_loss_partial<256>(s_hit, a.partial + 3 * MF_GRID_MAX);
     }
 }
 
-// phase 3: the owner occurrence of each touched row applies SparseAdam and releases the row
-struct AdamArgs {
+// ---------------------------------------------------------------------------
+// SparseAdam step (train() body). torch coalesces duplicate rows of the sparse gradient before the non-linear
+// update; here, without a sort:
+//   phase 1  k_rmf_fwd   : forward + loss + dL/dout per sample; every occurrence bumps its row's counter with ONE
+//                          returning atomic. The SECOND arriver of a row learns that the row is duplicated: it zeroes
+//                          its own slot of the [2B, d] gradient buffer and publishes the slot id in slot[row].
+//   phase 2  k_rmf_acc   : rows that occur once in the batch (almost every session row, most aid rows of the long tail):
+//                          gradient row in registers -> Adam on (p, m, v) in place, no gradient buffer traffic at all.
+//                          Duplicated rows: every occurrence adds its gradient row into the published slot
+//                          (global_atomic_add_f32, 16 bytes per lane, contiguous per row).
+//   phase 3  k_rmf_apply : the second arriver of each duplicated row applies Adam from its slot and clears the counter.
+// Counters are zero between steps (phase 2 / 3 clear exactly the rows they finish).
+// ---------------------------------------------------------------------------
+struct StepArgs {
     float* E1; float* m1; float* v1;
     float* E2; float* m2; float* v2;
     const int64_t* i1;
     const int64_t* i2;
-    int32_t* owner1;
-    int32_t* owner2;
-    const float* grad;
+    const int64_t* target;
     int64_t B;
+    int64_t n1, n2;
     int d;
     int G;
+    int loss_kind;
+    float* partial;
+    float* coef;            // [B] dL/dout / B
+    uint32_t* cnt1;         // [n1] occurrences of the row in this batch
+    uint32_t* cnt2;         // [n2] (== cnt1 for a shared table)
+    int32_t* slot1;         // [n1] duplicated rows: occurrence id whose gradient slot accumulates the row
+    int32_t* slot2;
+    uint8_t* role;          // [2B] 1: this occurrence applies its slot in phase 3
+    float* grad;            // [2B, d]
+    uint32_t* err;
     float omb1, omb2, eps, step_size;   // 1-beta1, 1-beta2
 };
 
@@ -177,28 +200,104 @@ __device__ __forceinline__ float adam1(float g, float& m, float& v, float omb1, 
     return -step_size * (m / (sqrtf(v) + eps));
 }
 
-__global__ __launch_bounds__(256) void k_mf_adam(AdamArgs a) {
+__device__ __forceinline__ void adam_row(float* E, float* M, float* V, float4 p, float4 g, const StepArgs& a) {
+    float4 m = ld4(M), v = ld4(V);
+    p.x += adam1(g.x, m.x, v.x, a.omb1, a.omb2, a.eps, a.step_size);
+    p.y += adam1(g.y, m.y, v.y, a.omb1, a.omb2, a.eps, a.step_size);
+    p.z += adam1(g.z, m.z, v.z, a.omb1, a.omb2, a.eps, a.step_size);
+    p.w += adam1(g.w, m.w, v.w, a.omb1, a.omb2, a.eps, a.step_size);
+    st4(E, p); st4(M, m); st4(V, v);
+}
+
+__device__ __forceinline__ bool rows_ok(const StepArgs& a, int64_t r1, int64_t r2) {
+    return (uint64_t)r1 < (uint64_t)a.n1 && (uint64_t)r2 < (uint64_t)a.n2;
+}
+
+__global__ __launch_bounds__(256) void k_rmf_fwd(StepArgs a) {
+    const int G = a.G;
+    const int gl = threadIdx.x & (G - 1);
+    const int64_t gpb = 256 / G;
+    float lsum = 0.f;
+    const float invB = 1.0f / (float)a.B;
+    for (int64_t b = (int64_t)blockIdx.x * gpb + threadIdx.x / G; b < a.B; b += (int64_t)gridDim.x * gpb) {
+        const int64_t r1 = a.i1[b], r2 = a.i2[b];
+        if (!rows_ok(a, r1, r2)) {
+            if (gl == 0) { atomicAdd(a.err, 1u); a.role[b] = 0; a.role[a.B + b] = 0; }
+            continue;
+        }
+        const float4 e1 = ld4(a.E1 + r1 * a.d + 4 * gl);
+        const float4 e2 = ld4(a.E2 + r2 * a.d + 4 * gl);
+        const float out = group_sum(dot4(e1, e2), G);
+        uint32_t old1 = 0, old2 = 0;
+        if (gl == 0) {
+            float l, g;
+            loss_grad(a.loss_kind, out, (float)a.target[b], &l, &g);
+            lsum += l;
+            a.coef[b] = g * invB;
+            old1 = atomicAdd(&a.cnt1[r1], 1u);
+            old2 = atomicAdd(&a.cnt2[r2], 1u);
+            a.role[b] = old1 == 1u;
+            a.role[a.B + b] = old2 == 1u;
+            if (old1 == 1u) a.slot1[r1] = (int32_t)b;
+            if (old2 == 1u) a.slot2[r2] = (int32_t)(a.B + b);
+        }
+        // the group leader's ranks, for every lane of the group (G <= 64 lanes inside one wave)
+        old1 = (uint32_t)__shfl((int)old1, (int)((threadIdx.x & 63) - gl), 64);
+        old2 = (uint32_t)__shfl((int)old2, (int)((threadIdx.x & 63) - gl), 64);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (old1 == 1u) st4(a.grad + b * a.d + 4 * gl, z);
+        if (old2 == 1u) st4(a.grad + (a.B + b) * a.d + 4 * gl, z);
+    }
+    block_loss_partial<256>(lsum, a.partial);
+}
+
+__device__ __forceinline__ void atomic_add4(float* p, float4 v) {
+    atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
+
+__global__ __launch_bounds__(256) void k_rmf_acc(StepArgs a) {
+    const int G = a.G;
+    const int gl = threadIdx.x & (G - 1);
+    const int64_t gpb = 256 / G;
+    for (int64_t b = (int64_t)blockIdx.x * gpb + threadIdx.x / G; b < a.B; b += (int64_t)gridDim.x * gpb) {
+        const int64_t r1 = a.i1[b], r2 = a.i2[b];
+        if (!rows_ok(a, r1, r2)) continue;
+        const uint32_t c1 = a.cnt1[r1], c2 = a.cnt2[r2];
+        const float c = a.coef[b];
+        float* p1 = a.E1 + r1 * a.d + 4 * gl;
+        float* p2 = a.E2 + r2 * a.d + 4 * gl;
+        const float4 e1 = ld4(p1), e2 = ld4(p2);
+        const float4 g1 = make_float4(c * e2.x, c * e2.y, c * e2.z, c * e2.w);
+        const float4 g2 = make_float4(c * e1.x, c * e1.y, c * e1.z, c * e1.w);
+        // every lane of the group has read both counters and both rows before anything is written
+        __builtin_amdgcn_wave_barrier();
+        if (c1 == 1u) {
+            adam_row(p1, a.m1 + r1 * a.d + 4 * gl, a.v1 + r1 * a.d + 4 * gl, e1, g1, a);
+            if (gl == 0) a.cnt1[r1] = 0;
+        } else {
+            atomic_add4(a.grad + (int64_t)a.slot1[r1] * a.d + 4 * gl, g1);
+        }
+        if (c2 == 1u) {
+            adam_row(p2, a.m2 + r2 * a.d + 4 * gl, a.v2 + r2 * a.d + 4 * gl, e2, g2, a);
+            if (gl == 0) a.cnt2[r2] = 0;
+        } else {
+            atomic_add4(a.grad + (int64_t)a.slot2[r2] * a.d + 4 * gl, g2);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rmf_apply(StepArgs a) {
     const int G = a.G;
     const int gl = threadIdx.x & (G - 1);
     const int64_t gpb = 256 / G;
     for (int64_t o = (int64_t)blockIdx.x * gpb + threadIdx.x / G; o < 2 * a.B; o += (int64_t)gridDim.x * gpb) {
+        if (!a.role[o]) continue;
         const bool first = o < a.B;
         const int64_t r = first ? a.i1[o] : a.i2[o - a.B];
-        int32_t* owner = first ? a.owner1 : a.owner2;
-        if (owner[r] != (int32_t)o) continue;
         float* E = (first ? a.E1 : a.E2) + r * a.d + 4 * gl;
-        float* M = (first ? a.m1 : a.m2) + r * a.d + 4 * gl;
-        float* V = (first ? a.v1 : a.v2) + r * a.d + 4 * gl;
-        const float4 g = ld4(a.grad + o * a.d + 4 * gl);
-        float4 p = ld4(E), m = ld4(M), v = ld4(V);
-        p.x += adam1(g.x, m.x, v.x, a.omb1, a.omb2, a.eps, a.step_size);
-        p.y += adam1(g.y, m.y, v.y, a.omb1, a.omb2, a.eps, a.step_size);
-        p.z += adam1(g.z, m.z, v.z, a.omb1, a.omb2, a.eps, a.step_size);
-        p.w += adam1(g.w, m.w, v.w, a.omb1, a.omb2, a.eps, a.step_size);
-        st4(E, p); st4(M, m); st4(V, v);
-        // all G lanes of the group must have read owner[r] before it is released
-        __builtin_amdgcn_wave_barrier();
-        if (gl == 0) owner[r] = OWNER_FREE;
+        adam_row(E, (first ? a.m1 : a.m2) + r * a.d + 4 * gl, (first ? a.v1 : a.v2) + r * a.d + 4 * gl, ld4(E),
+                 ld4(a.grad + o * a.d + 4 * gl), a);
+        if (gl == 0) (first ? a.cnt1 : a.cnt2)[r] = 0;
     }
 }
 
@@ -231,6 +330,8 @@ struct BprArgs {
     const int64_t* u;
     const int64_t* i;
     int64_t B;
+    int64_t n_users;
+    uint32_t* err;
     int64_t n_items;
     int d;
     int G;
@@ -262,6 +363,10 @@ __global__ __launch_bounds__(256) void k_bpr_hogwild(BprArgs a) {
     float lsum = 0.f;
     for (int64_t b = (int64_t)blockIdx.x * gpb + threadIdx.x / G; b < a.B; b += (int64_t)gridDim.x * gpb) {
         const int64_t u = a.u[b], i = a.i[b];
+        if ((uint64_t)u >= (uint64_t)a.n_users || (uint64_t)i >= (uint64_t)a.n_items) {   // skipped and reported (otto_mf_check)
+            if (gl == 0) atomicAdd(a.err, 1u);
+            continue;
+        }
         const int64_t j = bpr_negative(a.seed, a.epoch, (uint64_t)(a.row0 + b), i, a.n_items);
         float* pu = a.U + u * a.d + 4 * gl;
         float* pi = a.V + i * a.d + 4 * gl;
@@ -293,6 +398,10 @@ __global__ __launch_bounds__(256) void k_bpr_fwd(BprArgs a) {
     float lsum = 0.f;
     for (int64_t b = (int64_t)blockIdx.x * gpb + threadIdx.x / G; b < a.B; b += (int64_t)gridDim.x * gpb) {
         const int64_t u = a.u[b], i = a.i[b];
+        if ((uint64_t)u >= (uint64_t)a.n_users || (uint64_t)i >= (uint64_t)a.n_items) {
+            if (gl == 0) { atomicAdd(a.err, 1u); a.neg[b] = -1; }       // phases 2 and 3 skip the row on neg < 0
+            continue;
+        }
         const int64_t j = bpr_negative(a.seed, a.epoch, (uint64_t)(a.row0 + b), i, a.n_items);
         const float4 eu = ld4(a.U + u * a.d + 4 * gl), ei = ld4(a.V + i * a.d + 4 * gl), ej = ld4(a.V + j * a.d + 4 * gl);
         const float4 df = make_float4(ei.x - ej.x, ei.y - ej.y, ei.z - ej.z, ei.w - ej.w);
@@ -317,6 +426,7 @@ __global__ __launch_bounds__(256) void k_bpr_acc(BprArgs a) {
     const int64_t gpb = 256 / G;
     for (int64_t b = (int64_t)blockIdx.x * gpb + threadIdx.x / G; b < a.B; b += (int64_t)gridDim.x * gpb) {
         const int64_t u = a.u[b], i = a.i[b], j = a.neg[b];
+        if (j < 0) continue;
         const float s = a.coef[b], l2 = a.l2;
         const float4 eu = ld4(a.U + u * a.d + 4 * gl), ei = ld4(a.V + i * a.d + 4 * gl), ej = ld4(a.V + j * a.d + 4 * gl);
         float* gu = a.grad + (int64_t)a.ownerU[u] * a.d + 4 * gl;
@@ -339,6 +449,7 @@ __global__ __launch_bounds__(256) void k_bpr_apply(BprArgs a) {
     for (int64_t o = (int64_t)blockIdx.x * gpb + threadIdx.x / G; o < 3 * a.B; o += (int64_t)gridDim.x * gpb) {
         const int which = (int)(o / a.B);
         const int64_t b = o - (int64_t)which * a.B;
+        if (a.neg[b] < 0) continue;
         const int64_t r = which == 0 ? a.u[b] : (which == 1 ? a.i[b] : a.neg[b]);
         int32_t* owner = which == 0 ? a.ownerU : a.ownerV;
         if (owner[r] != (int32_t)o) continue;
@@ -546,13 +657,21 @@ using namespace otto;
 struct otto_mf_ctx {
     int64_t n1, n2, max_batch;
     int d, G, shared;
-    DevBuf owner1, owner2, grad, coef, neg, partial;
+    DevBuf owner1, owner2;          // BPR batch mode: row -> smallest occurrence id (OWNER_FREE between steps)
+    DevBuf cnt1, cnt2, slot1, slot2, role;   // SparseAdam step: occurrence counters (zero between steps), slots, roles
+    DevBuf grad, coef, neg, partial;
+    DevBuf err;                     // [0] u32: samples skipped because a row id was outside its table (sticky until read)
+    DevBuf sums;                    // [4] double: running sum|e|, sum e^2, hits, count of otto_mf_eval_sums
+    void release_all() {
+        DevBuf* all[] = {&owner1, &owner2, &cnt1, &cnt2, &slot1, &slot2, &role, &grad, &coef, &neg, &partial, &err, &sums};
+        for (DevBuf* b : all) b->release();
+    }
 };
 
 static int mf_grid(int64_t B, int G) {
     const int64_t gpb = 256 / G;
     int64_t g = (B + gpb - 1) / gpb;
-    const int64_t cap = 256 * 8;
+    const int64_t cap = MF_GRID_MAX;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
@@ -568,19 +687,25 @@ extern "C" int otto_mf_create(otto_mf_ctx** out, int64_t n1, int64_t n2, int32_t
     c->n1 = n1; c->n2 = shared_table ? n1 : n2; c->d = d; c->G = d / 4; c->shared = shared_table != 0;
     c->max_batch = max_batch;
     int rc = 0;
-    if ((rc = c->owner1.ensure((size_t)n1 * 4, 0, 0))) { delete c; return rc; }
-    if (!c->shared && (rc = c->owner2.ensure((size_t)n2 * 4, 0, 0))) { c->owner1.release(); delete c; return rc; }
-    if (hipMemset(c->owner1.p, 0x7F, (size_t)n1 * 4) != hipSuccess ||
-        (!c->shared && hipMemset(c->owner2.p, 0x7F, (size_t)n2 * 4) != hipSuccess)) {
-        set_error("hipMemset(owner) failed");
-        c->owner1.release(); c->owner2.release(); delete c;
-        return -5;
-    }
+    auto fail = [&](int code) { c->release_all(); delete c; return code; };
+    // per-row words of table 1 (and of table 2 unless the table is shared)
+    if ((rc = c->owner1.ensure((size_t)n1 * 4, 0, 0)) || (rc = c->cnt1.ensure((size_t)n1 * 4, 0, 0)) ||
+        (rc = c->slot1.ensure((size_t)n1 * 4, 0, 0)))
+        return fail(rc);
+    if (!c->shared && ((rc = c->owner2.ensure((size_t)n2 * 4, 0, 0)) || (rc = c->cnt2.ensure((size_t)n2 * 4, 0, 0)) ||
+                       (rc = c->slot2.ensure((size_t)n2 * 4, 0, 0))))
+        return fail(rc);
     if ((rc = c->grad.ensure((size_t)3 * max_batch * d * 4, 0, 0)) || (rc = c->coef.ensure((size_t)max_batch * 4, 0, 0)) ||
-        (rc = c->neg.ensure((size_t)max_batch * 8, 0, 0)) || (rc = c->partial.ensure((size_t)256 * 8 * 4, 0, 0))) {
-        c->owner1.release(); c->owner2.release(); c->grad.release(); c->coef.release(); c->neg.release(); c->partial.release();
-        delete c;
-        return rc;
+        (rc = c->neg.ensure((size_t)max_batch * 8, 0, 0)) || (rc = c->partial.ensure((size_t)4 * MF_GRID_MAX * 4, 0, 0)) ||
+        (rc = c->role.ensure((size_t)2 * max_batch, 0, 0)) || (rc = c->err.ensure(64, 0, 0)) || (rc = c->sums.ensure(64, 0, 0)))
+        return fail(rc);
+    bool ok = hipMemset(c->owner1.p, 0x7F, (size_t)n1 * 4) == hipSuccess && hipMemset(c->cnt1.p, 0, (size_t)n1 * 4) == hipSuccess &&
+              hipMemset(c->err.p, 0, 64) == hipSuccess && hipMemset(c->sums.p, 0, 64) == hipSuccess;
+    if (ok && !c->shared)
+        ok = hipMemset(c->owner2.p, 0x7F, (size_t)n2 * 4) == hipSuccess && hipMemset(c->cnt2.p, 0, (size_t)n2 * 4) == hipSuccess;
+    if (!ok) {
+        set_error("hipMemset of the per-row words failed");
+        return fail(-5);
     }
     *out = c;
     return 0;
@@ -588,7 +713,7 @@ extern "C" int otto_mf_create(otto_mf_ctx** out, int64_t n1, int64_t n2, int32_t
 
 extern "C" void otto_mf_destroy(otto_mf_ctx* c) {
     if (!c) return;
-    c->owner1.release(); c->owner2.release(); c->grad.release(); c->coef.release(); c->neg.release(); c->partial.release();
+    c->release_all();
     delete c;
 }
 
@@ -598,27 +723,67 @@ static int check_batch(otto_mf_ctx* c, int64_t B) {
     return 0;
 }
 
+extern "C" int otto_mf_check(otto_mf_ctx* c, int64_t* n_bad, void* stream) {
+    OTTO_REQUIRE(c, "null ctx");
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t bad = 0;
+    OTTO_HIP(hipMemcpyAsync(&bad, c->err.p, 4, hipMemcpyDeviceToHost, s));
+    OTTO_HIP(hipStreamSynchronize(s));
+    if (n_bad) *n_bad = (int64_t)bad;
+    if (bad) {
+        OTTO_HIP(hipMemsetAsync(c->err.p, 0, 4, s));
+        set_error("%u sample(s) carried a row id outside the embedding tables (n1 = %lld, n2 = %lld) and were skipped", bad,
+                  (long long)c->n1, (long long)c->n2);
+        return -22;
+    }
+    return 0;
+}
+
 extern "C" int otto_mf_forward(otto_mf_ctx* c, const float* E1, const float* E2, const int64_t* i1, const int64_t* i2,
                                int64_t B, float* pred, void* stream) {
     OTTO_TRY(check_batch(c, B));
     OTTO_REQUIRE(E1 && E2 && i1 && i2 && pred, "null argument");
-    FwdArgs a{E1, E2, i1, i2, nullptr, B, c->d, c->G, 0, pred, nullptr, nullptr, nullptr, nullptr};
+    FwdArgs a{E1, E2, i1, i2, nullptr, B, c->n1, c->n2, c->d, c->G, 0, pred, nullptr, c->err.as<uint32_t>()};
     k_mf_fwd<0><<<mf_grid(B, c->G), 256, 0, (hipStream_t)stream>>>(a);
+    OTTO_HIP(hipGetLastError());
+    return 0;
+}
+
+static int eval_impl(otto_mf_ctx* c, const float* E1, const float* E2, const int64_t* i1, const int64_t* i2,
+                     const int64_t* target, int64_t B, int32_t loss_kind, float* pred, float* loss_out, bool sums, void* stream) {
+    OTTO_TRY(check_batch(c, B));
+    OTTO_REQUIRE(E1 && E2 && i1 && i2 && target && loss_out, "null argument");
+    OTTO_REQUIRE(loss_kind == OTTO_MF_LOSS_MSE || loss_kind == OTTO_MF_LOSS_BCE, "unknown loss kind %d", loss_kind);
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = mf_grid(B, c->G);
+    FwdArgs a{E1, E2, i1, i2, target, B, c->n1, c->n2, c->d, c->G, loss_kind, pred, c->partial.as<float>(), c->err.as<uint32_t>()};
+    if (sums) {
+        k_mf_fwd<3><<<grid, 256, 0, s>>>(a);
+        k_loss_final<<<1, 256, 0, s>>>(c->partial.as<float>(), grid, 1.0f / (float)B, loss_out, c->sums.as<double>(), 3, MF_GRID_MAX, (double)B);
+    } else {
+        k_mf_fwd<1><<<grid, 256, 0, s>>>(a);
+        k_loss_final<<<1, 256, 0, s>>>(c->partial.as<float>(), grid, 1.0f / (float)B, loss_out, nullptr, 0, MF_GRID_MAX, 0.0);
+    }
     OTTO_HIP(hipGetLastError());
     return 0;
 }
 
 extern "C" int otto_mf_eval(otto_mf_ctx* c, const float* E1, const float* E2, const int64_t* i1, const int64_t* i2,
                             const int64_t* target, int64_t B, int32_t loss_kind, float* pred, float* loss_out, void* stream) {
-    OTTO_TRY(check_batch(c, B));
-    OTTO_REQUIRE(E1 && E2 && i1 && i2 && target && loss_out, "null argument");
-    OTTO_REQUIRE(loss_kind == OTTO_MF_LOSS_MSE || loss_kind == OTTO_MF_LOSS_BCE, "unknown loss kind %d", loss_kind);
+    return eval_impl(c, E1, E2, i1, i2, target, B, loss_kind, pred, loss_out, false, stream);
+}
+
+extern "C" int otto_mf_eval_sums(otto_mf_ctx* c, const float* E1, const float* E2, const int64_t* i1, const int64_t* i2,
+                                 const int64_t* target, int64_t B, int32_t loss_kind, float* pred, float* loss_out, void* stream) {
+    return eval_impl(c, E1, E2, i1, i2, target, B, loss_kind, pred, loss_out, true, stream);
+}
+
+extern "C" int otto_mf_read_sums(otto_mf_ctx* c, double* h_sums, int32_t reset, void* stream) {
+    OTTO_REQUIRE(c && h_sums, "null argument");
     hipStream_t s = (hipStream_t)stream;
-    const int grid = mf_grid(B, c->G);
-    FwdArgs a{E1, E2, i1, i2, target, B, c->d, c->G, loss_kind, pred, c->partial.as<float>(), nullptr, nullptr, nullptr};
-    k_mf_fwd<1><<<grid, 256, 0, s>>>(a);
-    k_loss_final<<<1, 256, 0, s>>>(c->partial.as<float>(), grid, 1.0f / (float)B, loss_out);
-    OTTO_HIP(hipGetLastError());
+    OTTO_HIP(hipMemcpyAsync(h_sums, c->sums.p, 32, hipMemcpyDeviceToHost, s));
+    OTTO_HIP(hipStreamSynchronize(s));
+    if (reset) OTTO_HIP(hipMemsetAsync(c->sums.p, 0, 32, s));
     return 0;
 }
 
@@ -633,19 +798,23 @@ extern "C" int otto_mf_step_sparse_adam(otto_mf_ctx* c, float* E1, float* m1, fl
     OTTO_REQUIRE(!c->shared || (E1 == E2 && m1 == m2 && v1 == v2), "shared_table context needs identical table pointers");
     hipStream_t s = (hipStream_t)stream;
     const int grid = mf_grid(B, c->G);
-    int32_t* o1 = c->owner1.as<int32_t>();
-    int32_t* o2 = c->shared ? o1 : c->owner2.as<int32_t>();
-    OTTO_HIP(hipMemsetAsync(c->grad.p, 0, (size_t)2 * B * c->d * 4, s));
-    FwdArgs f{E1, E2, i1, i2, target, B, c->d, c->G, loss_kind, nullptr, c->partial.as<float>(), c->coef.as<float>(), o1, o2};
-    k_mf_fwd<2><<<grid, 256, 0, s>>>(f);
-    k_loss_final<<<1, 256, 0, s>>>(c->partial.as<float>(), grid, 1.0f / (float)B, loss_out);
-    AccArgs ac{E1, E2, i1, i2, c->coef.as<float>(), o1, o2, c->grad.as<float>(), B, c->d, c->G};
-    k_mf_acc<<<grid, 256, 0, s>>>(ac);
     // torch: step_size = lr * sqrt(1 - beta2^t) / (1 - beta1^t), evaluated in double on the host
     const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
-    AdamArgs ad{E1, m1, v1, E2, m2, v2, i1, i2, o1, o2, c->grad.as<float>(), B, c->d, c->G, (float)(1.0 - beta1),
-                (float)(1.0 - beta2), (float)eps, (float)(lr * sqrt(bc2) / bc1)};
-    k_mf_adam<<<mf_grid(2 * B, c->G), 256, 0, s>>>(ad);
+    StepArgs a;
+    memset(&a, 0, sizeof a);
+    a.E1 = E1; a.m1 = m1; a.v1 = v1; a.E2 = E2; a.m2 = m2; a.v2 = v2;
+    a.i1 = i1; a.i2 = i2; a.target = target; a.B = B; a.n1 = c->n1; a.n2 = c->n2; a.d = c->d; a.G = c->G;
+    a.loss_kind = loss_kind;
+    a.partial = c->partial.as<float>(); a.coef = c->coef.as<float>();
+    a.cnt1 = c->cnt1.as<uint32_t>(); a.cnt2 = c->shared ? a.cnt1 : c->cnt2.as<uint32_t>();
+    a.slot1 = c->slot1.as<int32_t>(); a.slot2 = c->shared ? a.slot1 : c->slot2.as<int32_t>();
+    a.role = c->role.as<uint8_t>(); a.grad = c->grad.as<float>(); a.err = c->err.as<uint32_t>();
+    a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps;
+    a.step_size = (float)(lr * sqrt(bc2) / bc1);
+    k_rmf_fwd<<<grid, 256, 0, s>>>(a);
+    k_loss_final<<<1, 256, 0, s>>>(c->partial.as<float>(), grid, 1.0f / (float)B, loss_out, nullptr, 0, MF_GRID_MAX, 0.0);
+    k_rmf_acc<<<grid, 256, 0, s>>>(a);
+    k_rmf_apply<<<mf_grid(2 * B, c->G), 256, 0, s>>>(a);
     OTTO_HIP(hipGetLastError());
     return 0;
 }
@@ -662,7 +831,7 @@ extern "C" int otto_mf_bpr_step(otto_mf_ctx* c, float* U, float* V, const int64_
     const int grid = mf_grid(B, c->G);
     BprArgs a;
     memset(&a, 0, sizeof a);
-    a.U = U; a.V = V; a.u = u; a.i = i; a.B = B; a.n_items = c->n2; a.d = c->d; a.G = c->G;
+    a.U = U; a.V = V; a.u = u; a.i = i; a.B = B; a.n_users = c->n1; a.err = c->err.as<uint32_t>(); a.n_items = c->n2; a.d = c->d; a.G = c->G;
     a.seed = seed; a.epoch = epoch; a.row0 = row0; a.lr = lr; a.l2 = l2;
     a.partial = c->partial.as<float>(); a.neg_out = neg_out;
     if (mode == OTTO_MF_BPR_HOGWILD) {
@@ -675,7 +844,7 @@ extern "C" int otto_mf_bpr_step(otto_mf_ctx* c, float* U, float* V, const int64_
         k_bpr_acc<<<grid, 256, 0, s>>>(a);
         k_bpr_apply<<<mf_grid(3 * B, c->G), 256, 0, s>>>(a);
     }
-    k_loss_final<<<1, 256, 0, s>>>(c->partial.as<float>(), grid, 1.0f, loss_sum);
+    k_loss_final<<<1, 256, 0, s>>>(c->partial.as<float>(), grid, 1.0f, loss_sum, nullptr, 0, MF_GRID_MAX, 0.0);
     OTTO_HIP(hipGetLastError());
     return 0;
 }

@@ -30,6 +30,18 @@ class DeviceBatchLoader:
         return cls({name: table.column(name).to_numpy() for name in table.column_names if not name.startswith('__')},
                    batch_size, shuffle, drop_last, device, seed)
 
+    def check_ranges(self, limits):
+        """``limits``: column -> table size. Raises ValueError when a column holds an id outside [0, size): the YAML's
+        ``n_sessions`` / ``n_aids`` / ``n_embeddings`` do not cover the parquet (the kernels would skip such rows and the
+        epoch would end in ``OttoError``; this names the column up front)."""
+        for name, size in limits.items():
+            col = self.columns.get(name)
+            if col is None or col.numel() == 0:
+                continue
+            lo, hi = int(col.min()), int(col.max())
+            if lo < 0 or hi >= int(size):
+                raise ValueError(f"column '{name}' holds ids in [{lo}, {hi}] but its embedding table has {int(size)} rows")
+
     def __len__(self):
         return self.n // self.batch_size if self.drop_last else (self.n + self.batch_size - 1) // self.batch_size
 
@@ -42,6 +54,20 @@ class DeviceBatchLoader:
             else:
                 idx = perm[lo:hi]
                 yield {k: v[idx] for k, v in self.columns.items()}, None
+
+
+def _ts_seconds(ts):
+    """Event times as int64 SECONDS. ``train.pkl`` / ``test.pkl`` carry uint64 milliseconds
+    (``src/utilities/dataset_writer_pickle.py:59``), the split parquets seconds, the reference's 'time' branch expects a
+    datetime column (``torch_trainer.py:206`` ``.dt.seconds``): all three are accepted, with the same 'auto' rule as
+    ``events.frame_to_events`` (values above 1e11 are milliseconds). Signed, so ``ts_y - ts_x`` cannot wrap."""
+    v = np.asarray(ts)
+    if np.issubdtype(v.dtype, np.datetime64):
+        return v.astype('datetime64[s]').astype(np.int64)
+    v = v.astype(np.int64)
+    if len(v) and int(v.max()) > 10 ** 11:
+        v = v // 1000
+    return v
 
 
 def build_sessions_aids(df):
@@ -62,7 +88,7 @@ def build_aid_pairs(df, sampling_strategy='diff', chunk_size=30000, hour_differe
     """
     import pandas as pd
     rng = np.random.default_rng(seed)
-    df = df.sort_values(['session', 'ts'], kind='stable').reset_index(drop=True)
+    df = df.assign(ts=_ts_seconds(df['ts'])).sort_values(['session', 'ts'], kind='stable').reset_index(drop=True)
     if sampling_strategy == 'diff':
         s = df['session'].to_numpy()
         a = df['aid'].to_numpy().astype(np.int64)
@@ -86,7 +112,7 @@ def build_aid_pairs(df, sampling_strategy='diff', chunk_size=30000, hour_differe
             c = c.sample(frac=sample_frac, random_state=int(rng.integers(2 ** 31)))
             m = c.merge(c, on='session')
             m = m[m['aid_x'] != m['aid_y']]
-            dt = (m['ts_y'] - m['ts_x']).to_numpy().astype(np.float64) / 3600.0
+            dt = (m['ts_y'].to_numpy().astype(np.int64) - m['ts_x'].to_numpy().astype(np.int64)) / 3600.0     # hours, signed
             parts.append(pd.DataFrame({'aid_x': m['aid_x'].to_numpy(), 'aid_y': m['aid_y'].to_numpy(),
                                        'target': ((dt > 0) & (dt <= hour_difference)).astype(np.int64)}))
         allp = pd.concat(parts, ignore_index=True)

@@ -81,6 +81,29 @@ class MFEngine:
             _lib.check(self._lib.otto_mf_eval(self._ctx, _ptr(E1), _ptr(E2), _ptr(i1), _ptr(i2), _ptr(target), B,
                                               int(loss_kind), _ptr(pred), _ptr(loss_out), self._stream()), 'otto_mf_eval')
 
+    def eval_sums(self, E1, E2, i1, i2, target, loss_kind, loss_out, pred=None):
+        """``eval`` + the context's running score sums (sum |p - t|, sum (p - t)^2, hits at 0.5, count) grow by this batch:
+        validate() reads four doubles per epoch instead of every prediction (torch_trainer.py:144-158)."""
+        t = self.torch
+        self._tables(E1, E2)
+        B = self._idx(i1, i2, (('target', target),))
+        with t.cuda.device(self.device):
+            _lib.check(self._lib.otto_mf_eval_sums(self._ctx, _ptr(E1), _ptr(E2), _ptr(i1), _ptr(i2), _ptr(target), B,
+                                                   int(loss_kind), _ptr(pred), _ptr(loss_out), self._stream()), 'otto_mf_eval_sums')
+
+    def read_sums(self, reset=True):
+        """(sum |p - t|, sum (p - t)^2, hits, count) accumulated by ``eval_sums``; synchronises."""
+        buf = (C.c_double * 4)()
+        with self.torch.cuda.device(self.device):
+            _lib.check(self._lib.otto_mf_read_sums(self._ctx, buf, int(reset), self._stream()), 'otto_mf_read_sums')
+        return tuple(float(v) for v in buf)
+
+    def check(self):
+        """Raise ``OttoError`` if any kernel since the last call skipped a sample whose row id was outside its table
+        (the kernels range-check instead of faulting; ``nn.Embedding`` would raise IndexError in the reference)."""
+        with self.torch.cuda.device(self.device):
+            _lib.check(self._lib.otto_mf_check(self._ctx, None, self._stream()), 'otto_mf_check')
+
     def step_sparse_adam(self, E1, m1, v1, E2, m2, v2, i1, i2, target, loss_kind, lr, betas, eps, t_step, loss_out):
         """train() batch body with SparseAdam semantics; mean pre-update loss into ``loss_out``."""
         t = self.torch

@@ -73,37 +73,46 @@ def train(train_loader, model, criterion, optimizer, device, scheduler=None):
         optimizer.fused_step(model, i1, i2, targets, criterion, log.slot())
         if scheduler is not None:
             scheduler.step()
+    if log.n:
+        model.engine(1).check()          # out-of-range row ids were skipped in the kernels: raise here, once per epoch
     return float(np.mean(log.values()))
 
 
 def validate(val_loader, model, criterion, device, scores=False):
     """Validation loss (mean of batch means) and, with ``scores``, the score dict of
-    ``metrics.regression_scores`` / ``classification_scores`` (reference ``validate()``, ``:87-161``)."""
+    ``metrics.regression_scores`` / ``classification_scores`` (reference ``validate()``, ``:87-161``).
+
+    The reference moves every batch's predictions to the host and scores them with scikit-learn (``:144-158``); here the
+    eval kernel keeps running sums (MAE, MSE, accuracy) and only the classification model's ROC-AUC needs the predictions,
+    which stay on the device for one sort."""
     model.eval()
     dev = torch.device(device)
     log = _LossLog(dev)
     kind = loss_kind(criterion)
     E1, E2, _ = model._tables()
-    ground_truth, predictions = [], []
+    classification = isinstance(model, torch_modules.CollaborativeFiltering)
+    truth, predictions, eng = [], [], None
     with torch.no_grad():
         for inputs, _ in val_loader:
             i1, i2, targets = _unpack(model, inputs, device)
-            pred = torch.empty(i1.numel(), dtype=torch.float32, device=dev) if scores else None
-            model.engine(i1.numel()).eval(E1.data, E2.data, i1, i2, targets, kind, log.slot(), pred)
-            if scores:
-                ground_truth.append(targets)
+            if eng is None and scores:
+                model.engine(i1.numel()).read_sums(reset=True)       # start the epoch's running sums from zero
+            eng = model.engine(i1.numel())
+            if not scores:
+                eng.eval(E1.data, E2.data, i1, i2, targets, kind, log.slot(), None)
+                continue
+            pred = torch.empty(i1.numel(), dtype=torch.float32, device=dev) if classification else None
+            eng.eval_sums(E1.data, E2.data, i1, i2, targets, kind, log.slot(), pred)
+            if classification:
+                truth.append(targets)
                 predictions.append(pred)
     val_loss = float(np.mean(log.values()))
-    if scores:
-        y_true = torch.cat(ground_truth).float().cpu().numpy()
-        if isinstance(model, torch_modules.CollaborativeFiltering):
-            y_pred = torch.sigmoid(torch.cat(predictions)).cpu().numpy()
-            val_scores = metrics.classification_scores(y_true=y_true, y_pred=y_pred, threshold=0.5)
-        else:
-            y_pred = torch.cat(predictions).cpu().numpy()
-            val_scores = metrics.regression_scores(y_true=y_true, y_pred=y_pred)
-    else:
-        val_scores = None
+    val_scores = None
+    if eng is not None:
+        eng.check()
+    if scores and eng is not None:
+        auc = metrics.roc_auc(torch.cat(truth), torch.sigmoid(torch.cat(predictions))) if classification else None
+        val_scores = metrics.scores_from_sums(eng.read_sums(reset=True), classification, auc)
     return val_loss, val_scores
 
 
@@ -158,6 +167,8 @@ def run(config, df=None):
     else:
         model = torch_modules.MatrixFactorization(n_sessions=m['n_sessions'], n_aids=m['n_aids'], n_factors=m['n_factors'],
                                                   sparse=m['sparse'], dropout_probability=m['dropout_probability'])
+    train_loader.check_ranges({'x1': m['n_embeddings'], 'x2': m['n_embeddings']} if cls == 'CollaborativeFiltering'
+                              else {'session': m['n_sessions'], 'aid': m['n_aids']})
     if m['model_checkpoint_path'] is not None:
         model.load_state_dict(torch.load(m['model_checkpoint_path'], weights_only=True))
     model.to(device)
