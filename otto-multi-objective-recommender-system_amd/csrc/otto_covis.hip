@@ -950,7 +950,10 @@ __global__ void k_fill_items(ItemCount f, uint32_t n_aids, const uint64_t* item_
 // ---------------------------------------------------------------------------
 constexpr int MAX_K = 32;
 constexpr int MAX_KINDS = 4;
-constexpr int PK = 3;                    // kinds reduced per pass over the records
+#ifndef OTTO_PK
+#define OTTO_PK 3
+#endif
+constexpr int PK = OTTO_PK;                    // kinds reduced per pass over the records
 constexpr int PART_CHUNK_RUNS = 256;    // runs per partition-pass work item (<= 256 * 31 records: fits the LDS stage)
 constexpr int PART_STAGE = 8192;        // records staged in LDS per chunk
 constexpr int PART_STAGE_LOG2R = 10;    // staged (coalesced) scatter up to 1024 partitions, direct scatter above
@@ -1296,7 +1299,7 @@ struct ItemDesc {      // everything a workgroup needs about its item, fetched o
 #define OTTO_PH(i) do {} while (0)
 #endif
 // DBG: the timing diagnostics of `debug_skip` (wrong results) are compiled into a second instantiation only
-template <int LOG2T, int THREADS, int GROUP, bool PACKED, int MINW, int GU, bool DBG>
+template <int LOG2T, int THREADS, int GROUP, bool PACKED, int MINW, int GU, int INS_CH, bool DBG>
 __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     constexpr int T = 1 << LOG2T;
     constexpr int NW = THREADS / 64;
@@ -1306,19 +1309,26 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     constexpr bool DYNAMIC = THREADS != S_THREADS;   // work items dequeued with an atomic counter
     constexpr int EXCAP = 64;
     constexpr int PKD = WIDE ? 1 : PK;      // the time-weighted group has a single kind
+    // BOUND (type-weighted group): the kinds of a pass are linear in the same three counters with per-type coefficients
+    // between lo[t] = min_j coef[j][t] and hi[t] = max_j coef[j][t], so ONE lower-bound key KL and ONE upper-bound key KH
+    // per table slot bracket the key of every kind: KL <= key_j <= KH. With lambda <= the k-th largest KL, every kind's
+    // top-k lies inside {KH >= lambda}: one selection instead of PKD, then each kind ranks the short candidate list.
+    constexpr bool BOUND = GROUP == OTTO_COVIS_GROUP_TYPE && PKD > 1;
+    constexpr int CCAP = 256;               // candidate slots per item (more: exact single-wave fallback per kind)
     __shared__ uint64_t s_tab[PACKED ? T : 1];
     __shared__ uint32_t s_key[PACKED ? 1 : T];
     __shared__ uint32_t s_v[3][PACKED ? 1 : T];
-    __shared__ uint64_t s_lbw[NW > 1 ? PKD : 1][NW > 1 ? THREADS : 1];         // lane-best keys
+    __shared__ uint64_t s_lbw[NW > 1 ? (BOUND ? 1 : PKD) : 1][NW > 1 ? THREADS : 1];         // lane-best keys
     __shared__ uint32_t s_lby[1][(NW > 1 && WIDE) ? THREADS : 1];
-    __shared__ uint64_t s_exw[NW > 1 ? PKD : 1][NW > 1 ? EXCAP : 1];           // candidates above the threshold
+    __shared__ uint64_t s_exw[(NW > 1 || BOUND) ? PKD : 1][(NW > 1 || BOUND) ? EXCAP : 1];   // candidates above the threshold / rank broadcast
+    __shared__ uint16_t s_cand[BOUND ? CCAP : 1];                               // BOUND: slots of the candidates
     __shared__ uint32_t s_exy[1][(NW > 1 && WIDE) ? EXCAP : 1];
     __shared__ uint64_t s_thrw[PK];
     __shared__ uint32_t s_thry[PK];
     __shared__ uint32_t s_nex[PK];
     __shared__ uint32_t s_more;
     __shared__ uint32_t s_ovf;
-    constexpr int LISTCAP = 256;
+    constexpr int LISTCAP = BOUND ? S_CAP : 256;
     __shared__ uint16_t s_list[NW == 1 ? LISTCAP : 1];                         // one-wave bins: compacted valid slots
     __shared__ ItemDesc s_cur;
 
@@ -1411,7 +1421,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
 #pragma unroll
         for (int j = 0; j < PKD; ++j) {
             kclear(guess[j]);
-            if (use_guess && j < a.nk) {
+            if (use_guess && j < (BOUND ? 1 : a.nk)) {
                 const size_t o = (size_t)j * a.n_aids + x;
                 kload(guess[j], a.tau_w[o], WIDE ? a.tau_y[o] : 0u);
             }
@@ -1461,70 +1471,85 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 if (fb & 4u) atomicAdd(&s_v[2][PACKED ? 0 : found], 1u);
             }
         };
+        auto packed_add = [&](uint32_t rc) -> unsigned long long {
+            uint32_t add0, add1, add2;
+            if (GROUP == OTTO_COVIS_GROUP_TYPE) {
+                const uint32_t tyj = (rc >> REC_AID_BITS) & 3u;
+                add0 = tyj == 0; add1 = tyj == 1; add2 = tyj == 2;
+            } else {
+                const uint32_t fb = (rc >> 28) >> a.chan_shift;
+                add0 = fb & 1u; add1 = (fb >> 1) & 1u; add2 = (fb >> 2) & 1u;
+            }
+            return (unsigned long long)add0 | ((unsigned long long)add1 << 12) | ((unsigned long long)add2 << 24);
+        };
+        // CH records per lane are in flight at a time (more would spill: the 2^14 kernel runs at 128 VGPRs); a chunk no
+        // lane of the wave has a record for is skipped as a whole (small aids: most of a gather batch is empty)
         auto insert_batch = [&](auto ntag, const uint32_t* rc, const bool* okin, const uint32_t* e) {
             constexpr int N = decltype(ntag)::value;
+            constexpr int CH = INS_CH;
             if (DBG && (a.debug_skip & 8)) {                 // diagnostics: records are fetched but not inserted
 #pragma unroll
                 for (int u = 0; u < N; ++u)
                     if (okin[u] && rc[u] == 0xDEADBEEFu) s_ovf = 1;
                 return;
             }
-            bool ok[N];
-            uint32_t slot[N];
 #pragma unroll
-            for (int u = 0; u < N; ++u) {
-                ok[u] = okin[u];
-                if (GROUP == OTTO_COVIS_GROUP_FILTER && (((rc[u] >> 28) >> a.chan_shift) & 7u) == 0u) ok[u] = false;
-                slot[u] = rec_hash(rc[u]) >> (32 - LOG2T);
-            }
-            if (PACKED) {
-                unsigned long long add[N], old[N];
+            for (int c0 = 0; c0 < N; c0 += CH) {
+                bool ok[CH];
+                bool any = false;
 #pragma unroll
-                for (int u = 0; u < N; ++u) {
-                    uint32_t add0, add1, add2;
-                    if (GROUP == OTTO_COVIS_GROUP_TYPE) {
-                        const uint32_t tyj = (rc[u] >> REC_AID_BITS) & 3u;
-                        add0 = tyj == 0; add1 = tyj == 1; add2 = tyj == 2;
-                    } else {
-                        const uint32_t fb = (rc[u] >> 28) >> a.chan_shift;
-                        add0 = fb & 1u; add1 = (fb >> 1) & 1u; add2 = (fb >> 2) & 1u;
+                for (int q = 0; q < CH; ++q) {
+                    const int u = c0 + q;
+                    ok[q] = u < N && okin[u < N ? u : 0];
+                    if (GROUP == OTTO_COVIS_GROUP_FILTER && ok[q] && (((rc[u < N ? u : 0] >> 28) >> a.chan_shift) & 7u) == 0u) ok[q] = false;
+                    any = any || ok[q];
+                }
+                if (__ballot(any) == 0) continue;
+                if (PACKED) {
+                    uint32_t oldhi[CH];                       // high word of the slot before the CAS: 0xFFFFFFFF = was empty
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        const uint32_t r = rc[c0 + q < N ? c0 + q : 0];
+                        oldhi[q] = 0xFFFFFFFFu;
+                        if (ok[q]) {
+                            const unsigned long long o = atomicCAS((unsigned long long*)&s_tab[PACKED ? rec_hash(r) >> (32 - LOG2T) : 0],
+                                                                   (unsigned long long)TAB_EMPTY,
+                                                                   ((unsigned long long)(r & REC_AID_MASK) << 36) | packed_add(r));
+                            oldhi[q] = (uint32_t)(o >> 32);
+                        }
                     }
-                    add[u] = (unsigned long long)add0 | ((unsigned long long)add1 << 12) | ((unsigned long long)add2 << 24);
-                    old[u] = TAB_EMPTY;
-                    if (ok[u])
-                        old[u] = atomicCAS((unsigned long long*)&s_tab[PACKED ? slot[u] : 0], (unsigned long long)TAB_EMPTY,
-                                           ((unsigned long long)(rc[u] & REC_AID_MASK) << 36) | add[u]);
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        if (oldhi[q] == 0xFFFFFFFFu) continue;    // not a record, or a new key that went in with its first count
+                        const uint32_t r = rc[c0 + q < N ? c0 + q : 0];
+                        const uint32_t y = r & REC_AID_MASK, slot = rec_hash(r) >> (32 - LOG2T);
+                        if ((oldhi[q] >> 4) == y) atomicAdd((unsigned long long*)&s_tab[PACKED ? slot : 0], packed_add(r));
+                        else probe_on(y, slot, packed_add(r), (unsigned long long)y << 36);
+                    }
+                    continue;
+                }
+                uint32_t old[CH];
+#pragma unroll
+                for (int q = 0; q < CH; ++q) {
+                    const uint32_t r = rc[c0 + q < N ? c0 + q : 0];
+                    old[q] = KEY_EMPTY;
+                    if (ok[q]) old[q] = atomicCAS(&s_key[PACKED ? 0 : rec_hash(r) >> (32 - LOG2T)], KEY_EMPTY, r & REC_AID_MASK);
                 }
 #pragma unroll
-                for (int u = 0; u < N; ++u) {
-                    if (old[u] == TAB_EMPTY) continue;        // not a record, or a new key that went in with its first count
-                    const uint32_t y = rc[u] & REC_AID_MASK;
-                    if ((uint32_t)(old[u] >> 36) == y) atomicAdd((unsigned long long*)&s_tab[PACKED ? slot[u] : 0], add[u]);
-                    else probe_on(y, slot[u], add[u], (unsigned long long)y << 36);
-                }
-                return;
-            }
-            uint32_t old[N];
-#pragma unroll
-            for (int u = 0; u < N; ++u) {
-                old[u] = KEY_EMPTY;
-                if (ok[u]) old[u] = atomicCAS(&s_key[PACKED ? 0 : slot[u]], KEY_EMPTY, rc[u] & REC_AID_MASK);
-            }
-#pragma unroll
-            for (int u = 0; u < N; ++u) {
-                if (!ok[u]) continue;
-                const uint32_t y = rc[u] & REC_AID_MASK;
-                int found = (old[u] == KEY_EMPTY || old[u] == y) ? (int)slot[u] : -1;
-                if (found < 0) {
-                    uint32_t sl = slot[u];
-                    for (int probe = 1; probe < T; ++probe) {
+                for (int q = 0; q < CH; ++q) {
+                    if (!ok[q]) continue;
+                    const uint32_t r = rc[c0 + q < N ? c0 + q : 0];
+                    const uint32_t y = r & REC_AID_MASK;
+                    uint32_t sl = rec_hash(r) >> (32 - LOG2T);
+                    bool found = old[q] == KEY_EMPTY || old[q] == y;
+                    for (int probe = 1; !found && probe < T; ++probe) {
                         sl = (sl + 1) & (T - 1);
                         const uint32_t o2 = atomicCAS(&s_key[PACKED ? 0 : sl], KEY_EMPTY, y);
-                        if (o2 == KEY_EMPTY || o2 == y) { found = (int)sl; break; }
+                        found = o2 == KEY_EMPTY || o2 == y;
                     }
+                    if (!found) { s_ovf = 1; continue; }
+                    wide_add(r, sl, e[c0 + q < N ? c0 + q : 0]);
                 }
-                if (found < 0) { s_ovf = 1; continue; }
-                wide_add(rc[u], (uint32_t)found, e[u]);
             }
         };
 
@@ -1602,6 +1627,256 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         __syncthreads();
         OTTO_PH(3);
         const bool ovf = s_ovf != 0;
+        if constexpr (BOUND) {
+        if (ovf) {
+            // LDS table full: ask the host to redo this aid with twice the partitions
+            if (threadIdx.x == 0) {
+                a.flag[x] = 1;
+                a.boost[x] = (uint8_t)(lgR - l_log2r(a.cnt64[x], 0, a.l_cap, a.allow_packed) + 1);
+                atomicAdd(a.ovf_count, 1u);
+            }
+        } else if (!(DBG && (a.debug_skip & 2))) {
+            constexpr int MPL = T / THREADS;
+            // per-type bounds of the pass's weight vectors (wave-uniform)
+            uint32_t lo0 = a.coef[0][0], lo1 = a.coef[0][1], lo2 = a.coef[0][2], hi0 = lo0, hi1 = lo1, hi2 = lo2;
+            for (int j = 1; j < a.nk; ++j) {
+                lo0 = min(lo0, a.coef[j][0]); lo1 = min(lo1, a.coef[j][1]); lo2 = min(lo2, a.coef[j][2]);
+                hi0 = max(hi0, a.coef[j][0]); hi1 = max(hi1, a.coef[j][1]); hi2 = max(hi2, a.coef[j][2]);
+            }
+            // (y, counters) of table slot i; y == KEY_EMPTY: empty slot
+            auto slot_read = [&](int i, uint32_t& y, uint32_t& v0, uint32_t& v1, uint32_t& v2) {
+                if (PACKED) {
+                    const uint64_t v = s_tab[PACKED ? i : 0];
+                    y = v == TAB_EMPTY ? KEY_EMPTY : (uint32_t)(v >> 36);
+                    v0 = (uint32_t)v & 0xFFFu; v1 = (uint32_t)(v >> 12) & 0xFFFu; v2 = (uint32_t)(v >> 24) & 0xFFFu;
+                } else {
+                    y = s_key[PACKED ? 0 : i];
+                    v0 = s_v[0][PACKED ? 0 : i]; v1 = s_v[1][PACKED ? 0 : i]; v2 = s_v[2][PACKED ? 0 : i];
+                }
+            };
+            auto weight = [&](uint32_t v0, uint32_t v1, uint32_t v2, uint32_t c0, uint32_t c1, uint32_t c2) -> uint64_t {
+                if (PACKED) return (uint64_t)(v0 * c0 + v1 * c1 + v2 * c2);      // 12-bit counts x 8-bit weights: 32-bit math
+                return (uint64_t)v0 * c0 + (uint64_t)v1 * c1 + (uint64_t)v2 * c2;
+            };
+            auto slot_lohi = [&](int i, K& kl, K& kh) {
+                uint32_t y, v0, v1, v2;
+                slot_read(i, y, v0, v1, v2);
+                const bool valid = y != KEY_EMPTY;
+                kmake(kl, valid ? weight(v0, v1, v2, lo0, lo1, lo2) : 0ull, 0ull, y);
+                kmake(kh, valid ? weight(v0, v1, v2, hi0, hi1, hi2) : 0ull, 0ull, y);
+            };
+            auto slot_kind_key = [&](int i, int j) {
+                uint32_t y, v0, v1, v2;
+                slot_read(i, y, v0, v1, v2);
+                K key;
+                kmake(key, y != KEY_EMPTY ? weight(v0, v1, v2, a.coef[j][0], a.coef[j][1], a.coef[j][2]) : 0ull, 0ull, y);
+                return key;
+            };
+            // rank r of kind j -> output row (unpartitioned aid) or this partition's partial list; nv valid keys in the wave
+            auto emit_ranked = [&](int j, K key, uint32_t rank, int nv) {
+                const bool put = kvalid(key) && rank < (uint32_t)a.k;
+                if (lgR == 0) {
+                    const size_t o = ((size_t)(a.kind_base + j) * a.n_aids + x) * (size_t)a.k + rank;
+                    if (put) { a.out_y[o] = kaid(key); a.out_w[o] = kweight(key); }
+                    if (lane == 0) a.out_n[(size_t)(a.kind_base + j) * a.n_aids + x] = nv < a.k ? nv : a.k;
+                } else {
+                    const size_t base = ((size_t)it * a.nk + j) * (size_t)a.k;
+                    if (put) kstore(key, &a.part_w[base + rank], &a.part_y[base + rank]);
+                    if ((int)lane < a.k && (int)lane >= nv) { K z; kclear(z); kstore(z, &a.part_w[base + lane], &a.part_y[base + lane]); }
+                }
+            };
+            // exact top-k of kind j by ONE wave over the whole table (two scans): only when the candidate list overflowed
+            auto wave_exact_topk = [&](int j) {
+                K lb;
+                kclear(lb);
+                int bi = -1;
+                for (int i = (int)lane; i < T; i += 64) {
+                    const K key = slot_kind_key(i, j);
+                    if (kbetter(key, lb)) { lb = key; bi = i; }
+                }
+                K best = lb;
+                wave_bitonic_sort_desc(best);
+                for (int i = (int)lane; i < T; i += 64) {
+                    K key = slot_kind_key(i, j);
+                    if (i == bi) kclear(key);
+                    wave_topk_push(best, key, a.k);
+                }
+                emit(j, best);
+            };
+            // kind j from the candidate list s_cand[0, ncand): rank = number of better candidates (keys are distinct: one
+            // per aid_y), read back from LDS with uniform addresses -- no sorting network, every iteration independent
+            auto finish_kind = [&](int j, uint32_t ncand) {
+                if (ncand <= 64u) {
+                    K key;
+                    kclear(key);
+                    if (lane < ncand) key = slot_kind_key((int)s_cand[lane], j);
+                    s_exw[j][lane] = key.c;
+                    wave_lds_sync();
+                    uint32_t rank = 0;
+#pragma unroll 4
+                    for (uint32_t i = 0; i < ncand; ++i) rank += s_exw[j][i] > key.c ? 1u : 0u;
+                    emit_ranked(j, key, rank, __popcll(__ballot(kvalid(key))));
+                } else {
+                    K c4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t idx = (uint32_t)q * 64u + lane;
+                        kclear(c4[q]);
+                        if (idx < ncand) c4[q] = slot_kind_key((int)s_cand[idx], j);
+                    }
+                    K best;
+                    wave_topk_select<4, K>(c4, a.k, best);
+                    emit(j, best);
+                }
+            };
+            if (NW == 1) {
+                // ---- one wave owns the table: compact the occupied slots, then select on the bound keys ----
+                uint32_t nvalid = 0;
+#pragma unroll
+                for (int q = 0; q < MPL; ++q) {
+                    const int i = q * THREADS + threadIdx.x;
+                    const bool v = PACKED ? (s_tab[PACKED ? i : 0] != TAB_EMPTY) : (s_key[PACKED ? 0 : i] != KEY_EMPTY);
+                    const uint64_t m = __ballot(v);
+                    const uint32_t pos = nvalid + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (v && pos < (uint32_t)LISTCAP) s_list[NW == 1 ? pos : 0] = (uint16_t)i;
+                    nvalid += (uint32_t)__popcll(m);
+                }
+                wave_lds_sync();
+                uint32_t ncand = 0;
+                bool overflow = nvalid > (uint32_t)LISTCAP;          // cannot happen (an S aid has <= S_CAP records); exact fallback anyway
+                if (nvalid <= 32u || nvalid <= (uint32_t)a.k) {
+                    // every occupied slot is a candidate
+                    if (lane < nvalid) s_cand[lane] = s_list[NW == 1 ? lane : 0];
+                    ncand = nvalid;
+                } else if (!overflow) {
+                    // lane-best of KL over the lane's list entries, one 64-lane sort, threshold = k-th best lane-best
+                    // (a lower bound of the k-th largest KL), then every entry with KH >= threshold is a candidate
+                    K lb;
+                    kclear(lb);
+                    for (uint32_t li = lane; li < nvalid; li += 64u) {
+                        K kl, kh;
+                        slot_lohi((int)s_list[NW == 1 ? li : 0], kl, kh);
+                        if (kbetter(kl, lb)) lb = kl;
+                    }
+                    wave_bitonic_sort_desc(lb);
+                    const K thr = kshfl(lb, a.k - 1);
+                    for (uint32_t l0 = 0; l0 < nvalid; l0 += 64u) {
+                        const uint32_t li = l0 + lane;
+                        bool c = false;
+                        uint16_t sl = 0;
+                        if (li < nvalid) {
+                            K kl, kh;
+                            sl = s_list[NW == 1 ? li : 0];
+                            slot_lohi((int)sl, kl, kh);
+                            c = !kbetter(thr, kh);
+                        }
+                        const uint64_t m = __ballot(c);
+                        const uint32_t pos = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (c && pos < (uint32_t)CCAP) s_cand[pos] = sl;
+                        ncand += (uint32_t)__popcll(m);
+                    }
+                    overflow = ncand > (uint32_t)CCAP;
+                }
+                wave_lds_sync();
+                for (int j = 0; j < a.nk; ++j) {
+                    if (overflow) wave_exact_topk(j);
+                    else finish_kind(j, ncand);
+                }
+                wave_lds_sync();
+            } else {
+                bool done_fast = false;
+                if (use_guess && kvalid(guess[0])) {                 // uniform: every thread loaded the same word
+                    // ---- one pass: candidates = KH >= guess; exact if at least k slots have KL >= guess ----
+                    if (threadIdx.x < 2) s_nex[threadIdx.x] = 0;
+                    if (threadIdx.x == 0) s_more = 0;
+                    __syncthreads();
+                    uint32_t cl = 0;
+#pragma unroll 2
+                    for (int q = 0; q < MPL; ++q) {
+                        const int i = q * THREADS + threadIdx.x;
+                        K kl, kh;
+                        slot_lohi(i, kl, kh);
+                        if (kvalid(kh) && !kbetter(guess[0], kh)) {
+                            const uint32_t pos = atomicAdd(&s_nex[0], 1u);
+                            if (pos < (uint32_t)CCAP) s_cand[pos] = (uint16_t)i;
+                            else s_more = 1;
+                        }
+                        cl += (kvalid(kl) && !kbetter(guess[0], kl)) ? 1u : 0u;
+                    }
+                    for (int o = 32; o > 0; o >>= 1) cl += __shfl_xor(cl, o, 64);
+                    if (lane == 0 && cl) atomicAdd(&s_nex[1], cl);
+                    __syncthreads();
+                    const bool ok = s_more == 0 && s_nex[1] >= (uint32_t)a.k;
+#ifdef OTTO_PHASE_PROF
+                    if (threadIdx.x == 0) { ph[8]++; if (ok) ph[9]++; else if (s_more) ph[11]++; else ph[10]++; }
+#endif
+                    if (ok) {
+                        if (wid < a.nk) finish_kind(wid, s_nex[0]);
+                        done_fast = true;
+                    }
+                    __syncthreads();
+                }
+                OTTO_PH(7);
+                if (!done_fast) {
+                    // ---- P1 every lane: best KL of its slots. P2 wave 0: k-th best of the 64 group bests = threshold
+                    //      (a lower bound of the k-th largest KL). P3 every lane: slots with KH >= threshold -> candidate
+                    //      list. P4 wave j: rank the candidates for kind j. ----
+                    K lb;
+                    kclear(lb);
+                    uint32_t nonempty = 0;
+#pragma unroll 2
+                    for (int q = 0; q < MPL; ++q) {
+                        K kl, kh;
+                        slot_lohi(q * THREADS + threadIdx.x, kl, kh);
+                        if (kvalid(kl)) nonempty |= 1u << q;
+                        if (kbetter(kl, lb)) lb = kl;
+                    }
+                    s_lbw[0][NW > 1 ? threadIdx.x : 0] = lb.c;
+                    if (threadIdx.x < 2) s_nex[threadIdx.x] = 0;
+                    if (threadIdx.x == 0) s_more = 0;
+                    __syncthreads();
+                    OTTO_PH(4);
+                    if (wid == 0) {
+                        K gb;
+                        kclear(gb);
+#pragma unroll
+                        for (int q = 0; q < NW; ++q) {
+                            const K o{s_lbw[0][NW > 1 ? q * 64 + lane : 0]};
+                            if (kbetter(o, gb)) gb = o;
+                        }
+                        wave_bitonic_sort_desc(gb);
+                        const K thr = kshfl(gb, a.k - 1);
+                        if (lane == 0) s_thrw[0] = thr.c;
+                        // lane 31: a lower bound of this partition's 32nd best KL = the guess for the aid's other partitions
+                        if (use_guess && lane == 31u && kvalid(gb)) a.tau_w[x] = gb.c;
+                    }
+                    OTTO_PH(5);
+                    __syncthreads();
+                    const K thr{s_thrw[0]};
+                    uint32_t rem = nonempty;
+                    while (rem != 0) {
+                        const int q = __builtin_ctz(rem);
+                        rem &= rem - 1u;
+                        const int i = q * THREADS + threadIdx.x;
+                        K kl, kh;
+                        slot_lohi(i, kl, kh);
+                        if (!kbetter(thr, kh)) {
+                            const uint32_t pos = atomicAdd(&s_nex[0], 1u);
+                            if (pos < (uint32_t)CCAP) s_cand[pos] = (uint16_t)i;
+                            else s_more = 1;
+                        }
+                    }
+                    __syncthreads();
+                    OTTO_PH(6);
+                    if (wid < a.nk) {
+                        if (s_more) wave_exact_topk(wid);
+                        else finish_kind(wid, s_nex[0]);
+                    }
+                    OTTO_PH(7);
+                }
+            }
+        }
+        } else {
         bool fast_done = false;
         if (NW > 1 && use_guess && !ovf && !(DBG && (a.debug_skip & 2))) {
             constexpr int MPLG = T / THREADS;
@@ -1871,6 +2146,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             }
             }
         }
+        }   // !BOUND
         // ---- hand the prefetched next item over ----
         if (DYNAMIC) {
             __syncthreads();                       // every thread is done with s_cur's consumers and the table
@@ -2147,6 +2423,7 @@ struct otto_covis_ctx {
     int items_allow_packed = -1;   // layout rule the L item list was built with (-1: not built)
     DevBuf tau_w, tau_y;           // threshold guesses of partitioned heavy aids (per reduce pass)
     int guess = 1;                 // option "guess": single-pass top-k from a sibling partition's threshold
+    int ins_ch = 1;                // option "ins_ch": records per lane whose first-probe CAS is in flight together (1, 2, 4)
     DevBuf exp_run_pos, exp_rec_pos, exp_totals;
     uint64_t exp_n_runs[64] = {0}, exp_n_recs[64] = {0};
     int exp_planned = 0;
@@ -2505,9 +2782,13 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
 #define OTTO_LAUNCH_REDUCE(grid, threads, args, ...)                                                   \
     do {                                                                                               \
         if (GROUP == OTTO_COVIS_GROUP_TYPE && (args).debug_skip)                                       \
-            k_reduce<__VA_ARGS__, GROUP == OTTO_COVIS_GROUP_TYPE><<<grid, threads, 0, s>>>(args);      \
+            k_reduce<__VA_ARGS__, 1, GROUP == OTTO_COVIS_GROUP_TYPE><<<grid, threads, 0, s>>>(args);   \
+        else if (c->ins_ch == 4)                                                                       \
+            k_reduce<__VA_ARGS__, 4, false><<<grid, threads, 0, s>>>(args);                            \
+        else if (c->ins_ch == 2)                                                                       \
+            k_reduce<__VA_ARGS__, 2, false><<<grid, threads, 0, s>>>(args);                            \
         else                                                                                           \
-            k_reduce<__VA_ARGS__, false><<<grid, threads, 0, s>>>(args);                               \
+            k_reduce<__VA_ARGS__, 1, false><<<grid, threads, 0, s>>>(args);                            \
     } while (0)
 
 template <int GROUP>
@@ -2734,6 +3015,11 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
     if (strcmp(name, "debug_skip") == 0) { c->debug_skip = (int)value; return 0; }   // timing diagnostics, results invalid
     if (strcmp(name, "packed_heavy") == 0) { c->packed_heavy = value != 0; c->index_valid = false; return 0; }
     if (strcmp(name, "bucket_index") == 0) { c->bucket_index = value != 0; return 0; }
+    if (strcmp(name, "ins_ch") == 0) {
+        OTTO_REQUIRE(value == 1 || value == 2 || value == 4, "ins_ch must be 1, 2 or 4");
+        c->ins_ch = (int)value;
+        return 0;
+    }
     if (strcmp(name, "guess") == 0) { c->guess = value != 0; return 0; }           // threshold guessing on/off (A/B)
     if (strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }           // fused in-order expansion on/off (A/B)
     if (strcmp(name, "fast_path") == 0) { c->fast_path = value != 0; return 0; }   // gap-free window kernel on/off (A/B)
