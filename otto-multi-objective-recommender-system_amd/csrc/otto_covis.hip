@@ -994,7 +994,7 @@ struct ReduceArgs {
     uint32_t l_cap;                // records per L partition the item lists were sized for
     int debug_skip;                // diagnostics only (wrong results): 1 skip gather, 2 skip top-k, 4 skip table init, 8 skip inserts
 #ifdef OTTO_PHASE_PROF
-    unsigned long long* prof;      // [8] summed shader-clock ticks of thread 0 per phase
+    unsigned long long* prof;      // [16] summed shader-clock ticks of thread 0 per phase + path counters
 #endif
 };
 
@@ -1313,13 +1313,18 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     // between lo[t] = min_j coef[j][t] and hi[t] = max_j coef[j][t], so ONE lower-bound key KL and ONE upper-bound key KH
     // per table slot bracket the key of every kind: KL <= key_j <= KH. With lambda <= the k-th largest KL, every kind's
     // top-k lies inside {KH >= lambda}: one selection instead of PKD, then each kind ranks the short candidate list.
-    constexpr bool BOUND = GROUP == OTTO_COVIS_GROUP_TYPE && PKD > 1;
+    constexpr bool BOUND = GROUP == OTTO_COVIS_GROUP_TYPE && PKD > 1 && NW == 1;   // one-wave bin only: see DESIGN.md (heavy aids: the band is too wide)
     constexpr int CCAP = 256;               // candidate slots per item (more: exact single-wave fallback per kind)
     __shared__ uint64_t s_tab[PACKED ? T : 1];
     __shared__ uint32_t s_key[PACKED ? 1 : T];
     __shared__ uint32_t s_v[3][PACKED ? 1 : T];
-    __shared__ uint64_t s_lbw[NW > 1 ? (BOUND ? 1 : PKD) : 1][NW > 1 ? THREADS : 1];         // lane-best keys
-    __shared__ uint32_t s_lby[1][(NW > 1 && WIDE) ? THREADS : 1];
+    // Multi-wave bins keep a dense list of the occupied slots, appended to when a key enters the table: the top-k passes
+    // walk ceil(occupied / THREADS) entries per lane instead of T / THREADS slots (the tables run 15 - 40 % full), and the
+    // table is cleared through the list. More distinct keys than OCAP: the passes fall back to walking the table.
+    constexpr int OCAP = NW == 1 ? 1 : (LOG2T == 12 ? 2048 : (LOG2T == 14 ? 12288 : (THREADS == 512 ? 5632 : 6144)));
+    __shared__ uint16_t s_occ[OCAP];
+    __shared__ uint32_t s_nocc;
+    __shared__ uint16_t s_lbi[NW > 1 ? PKD : 1][NW > 1 ? THREADS : 1];         // slot of every lane's best key per kind (0xFFFF: none)
     __shared__ uint64_t s_exw[(NW > 1 || BOUND) ? PKD : 1][(NW > 1 || BOUND) ? EXCAP : 1];   // candidates above the threshold / rank broadcast
     __shared__ uint16_t s_cand[BOUND ? CCAP : 1];                               // BOUND: slots of the candidates
     __shared__ uint32_t s_exy[1][(NW > 1 && WIDE) ? EXCAP : 1];
@@ -1335,7 +1340,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     const int wid = threadIdx.x >> 6;
     const unsigned lane = lane_id();
 #ifdef OTTO_PHASE_PROF
-    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = clock64();
+    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = clock64();
 #endif
 
     // ---- item pipeline: (index, item word, run range, bucket range) of the NEXT item are fetched while the
@@ -1389,6 +1394,21 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         fetch_ranges(cur);
     }
     uint32_t sidx = blockIdx.x;          // static schedule: position in the work list
+    auto clear_slot = [&](int i) {
+        if (PACKED) {
+            s_tab[PACKED ? i : 0] = TAB_EMPTY;
+        } else {
+            s_key[PACKED ? 0 : i] = KEY_EMPTY;
+            s_v[0][PACKED ? 0 : i] = 0; s_v[1][PACKED ? 0 : i] = 0; s_v[2][PACKED ? 0 : i] = 0;
+        }
+    };
+    auto clear_table = [&]() {
+        for (int i = threadIdx.x; i < T; i += THREADS) clear_slot(i);
+    };
+    if (NW > 1) {
+        clear_table();
+        if (threadIdx.x == 0) { s_nocc = 0; s_ovf = 0; }
+    }
 
     for (;;) {
         if (DYNAMIC) {
@@ -1426,29 +1446,40 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 kload(guess[j], a.tau_w[o], WIDE ? a.tau_y[o] : 0u);
             }
         }
-        if (!(DBG && (a.debug_skip & 4))) {
-            for (int i = threadIdx.x; i < T; i += THREADS) {
-                if (PACKED) {
-                    s_tab[i] = TAB_EMPTY;
-                } else {
-                    s_key[i] = KEY_EMPTY;
-                    s_v[0][i] = 0; s_v[1][i] = 0; s_v[2][i] = 0;
-                }
-            }
+        if (NW == 1 && !(DBG && (a.debug_skip & 4))) clear_table();      // multi-wave bins: cleared at the end of the previous item
+        if (NW == 1) {                       // multi-wave bins: s_ovf is reset with the table at the end of the previous item
+            s_ovf = 0;
+            wave_lds_sync();
         }
-        if (threadIdx.x == 0) s_ovf = 0;
-        __syncthreads();
         OTTO_PH(1);
 
         // Records go into the table N at a time: the first-probe CAS of all N is issued back to back (N independent LDS
         // round trips in flight per lane instead of one), then hits (key already there: add) and misses (next probe) are
         // resolved. `e` = time extra (GROUP_TIME only). CAS first, no read: a new key (most records) costs ONE LDS
         // operation in the packed layout -- it goes in together with its first count.
+        // a key entered the table at `slot`: append the slot to the dense list. Wave-aggregated: one counter bump per wave
+        // and insert round (every lane of the wave calls this together); note_new1 is the per-lane form of the probe loops
+        auto note_new = [&](bool isnew, uint32_t slot) {
+            if (NW == 1) return;
+            const uint64_t m = __ballot(isnew);
+            if (m == 0) return;
+            const int leader = __ffsll((unsigned long long)m) - 1;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(&s_nocc, (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, leader, 64);
+            const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (isnew && pos < (uint32_t)OCAP) s_occ[NW > 1 ? pos : 0] = (uint16_t)slot;
+        };
+        auto note_new1 = [&](uint32_t slot) {
+            if (NW == 1) return;
+            const uint32_t pos = atomicAdd(&s_nocc, 1u);
+            if (pos < (uint32_t)OCAP) s_occ[NW > 1 ? pos : 0] = (uint16_t)slot;
+        };
         auto probe_on = [&](uint32_t y, uint32_t slot, unsigned long long add, unsigned long long fresh) {   // packed: slots after the first
             for (int probe = 1; probe < T; ++probe) {
                 slot = (slot + 1) & (T - 1);
                 const unsigned long long old = atomicCAS((unsigned long long*)&s_tab[PACKED ? slot : 0], (unsigned long long)TAB_EMPTY, fresh | add);
-                if (old == TAB_EMPTY) return;
+                if (old == TAB_EMPTY) { note_new1(slot); return; }
                 if ((uint32_t)(old >> 36) == y) {
                     atomicAdd((unsigned long long*)&s_tab[PACKED ? slot : 0], add);
                     return;
@@ -1517,6 +1548,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                                                                    ((unsigned long long)(r & REC_AID_MASK) << 36) | packed_add(r));
                             oldhi[q] = (uint32_t)(o >> 32);
                         }
+                        note_new(ok[q] && oldhi[q] == 0xFFFFFFFFu, rec_hash(r) >> (32 - LOG2T));
                     }
 #pragma unroll
                     for (int q = 0; q < CH; ++q) {
@@ -1534,6 +1566,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                     const uint32_t r = rc[c0 + q < N ? c0 + q : 0];
                     old[q] = KEY_EMPTY;
                     if (ok[q]) old[q] = atomicCAS(&s_key[PACKED ? 0 : rec_hash(r) >> (32 - LOG2T)], KEY_EMPTY, r & REC_AID_MASK);
+                    note_new(ok[q] && old[q] == KEY_EMPTY, rec_hash(r) >> (32 - LOG2T));
                 }
 #pragma unroll
                 for (int q = 0; q < CH; ++q) {
@@ -1545,6 +1578,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                     for (int probe = 1; !found && probe < T; ++probe) {
                         sl = (sl + 1) & (T - 1);
                         const uint32_t o2 = atomicCAS(&s_key[PACKED ? 0 : sl], KEY_EMPTY, y);
+                        if (o2 == KEY_EMPTY) note_new1(sl);
                         found = o2 == KEY_EMPTY || o2 == y;
                     }
                     if (!found) { s_ovf = 1; continue; }
@@ -1729,7 +1763,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                     emit(j, best);
                 }
             };
-            if (NW == 1) {
+            {
                 // ---- one wave owns the table: compact the occupied slots, then select on the bound keys ----
                 uint32_t nvalid = 0;
 #pragma unroll
@@ -1783,149 +1817,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                     else finish_kind(j, ncand);
                 }
                 wave_lds_sync();
-            } else {
-                bool done_fast = false;
-                if (use_guess && kvalid(guess[0])) {                 // uniform: every thread loaded the same word
-                    // ---- one pass: candidates = KH >= guess; exact if at least k slots have KL >= guess ----
-                    if (threadIdx.x < 2) s_nex[threadIdx.x] = 0;
-                    if (threadIdx.x == 0) s_more = 0;
-                    __syncthreads();
-                    uint32_t cl = 0;
-#pragma unroll 2
-                    for (int q = 0; q < MPL; ++q) {
-                        const int i = q * THREADS + threadIdx.x;
-                        K kl, kh;
-                        slot_lohi(i, kl, kh);
-                        if (kvalid(kh) && !kbetter(guess[0], kh)) {
-                            const uint32_t pos = atomicAdd(&s_nex[0], 1u);
-                            if (pos < (uint32_t)CCAP) s_cand[pos] = (uint16_t)i;
-                            else s_more = 1;
-                        }
-                        cl += (kvalid(kl) && !kbetter(guess[0], kl)) ? 1u : 0u;
-                    }
-                    for (int o = 32; o > 0; o >>= 1) cl += __shfl_xor(cl, o, 64);
-                    if (lane == 0 && cl) atomicAdd(&s_nex[1], cl);
-                    __syncthreads();
-                    const bool ok = s_more == 0 && s_nex[1] >= (uint32_t)a.k;
-#ifdef OTTO_PHASE_PROF
-                    if (threadIdx.x == 0) { ph[8]++; if (ok) ph[9]++; else if (s_more) ph[11]++; else ph[10]++; }
-#endif
-                    if (ok) {
-                        if (wid < a.nk) finish_kind(wid, s_nex[0]);
-                        done_fast = true;
-                    }
-                    __syncthreads();
-                }
-                OTTO_PH(7);
-                if (!done_fast) {
-                    // ---- P1 every lane: best KL of its slots. P2 wave 0: k-th best of the 64 group bests = threshold
-                    //      (a lower bound of the k-th largest KL). P3 every lane: slots with KH >= threshold -> candidate
-                    //      list. P4 wave j: rank the candidates for kind j. ----
-                    K lb;
-                    kclear(lb);
-                    uint32_t nonempty = 0;
-#pragma unroll 2
-                    for (int q = 0; q < MPL; ++q) {
-                        K kl, kh;
-                        slot_lohi(q * THREADS + threadIdx.x, kl, kh);
-                        if (kvalid(kl)) nonempty |= 1u << q;
-                        if (kbetter(kl, lb)) lb = kl;
-                    }
-                    s_lbw[0][NW > 1 ? threadIdx.x : 0] = lb.c;
-                    if (threadIdx.x < 2) s_nex[threadIdx.x] = 0;
-                    if (threadIdx.x == 0) s_more = 0;
-                    __syncthreads();
-                    OTTO_PH(4);
-                    if (wid == 0) {
-                        K gb;
-                        kclear(gb);
-#pragma unroll
-                        for (int q = 0; q < NW; ++q) {
-                            const K o{s_lbw[0][NW > 1 ? q * 64 + lane : 0]};
-                            if (kbetter(o, gb)) gb = o;
-                        }
-                        wave_bitonic_sort_desc(gb);
-                        const K thr = kshfl(gb, a.k - 1);
-                        if (lane == 0) s_thrw[0] = thr.c;
-                        // lane 31: a lower bound of this partition's 32nd best KL = the guess for the aid's other partitions
-                        if (use_guess && lane == 31u && kvalid(gb)) a.tau_w[x] = gb.c;
-                    }
-                    OTTO_PH(5);
-                    __syncthreads();
-                    const K thr{s_thrw[0]};
-                    uint32_t rem = nonempty;
-                    while (rem != 0) {
-                        const int q = __builtin_ctz(rem);
-                        rem &= rem - 1u;
-                        const int i = q * THREADS + threadIdx.x;
-                        K kl, kh;
-                        slot_lohi(i, kl, kh);
-                        if (!kbetter(thr, kh)) {
-                            const uint32_t pos = atomicAdd(&s_nex[0], 1u);
-                            if (pos < (uint32_t)CCAP) s_cand[pos] = (uint16_t)i;
-                            else s_more = 1;
-                        }
-                    }
-                    __syncthreads();
-                    OTTO_PH(6);
-                    if (wid < a.nk) {
-                        if (s_more) wave_exact_topk(wid);
-                        else finish_kind(wid, s_nex[0]);
-                    }
-                    OTTO_PH(7);
-                }
             }
         }
-        } else {
+        } else if constexpr (NW == 1) {
         bool fast_done = false;
-        if (NW > 1 && use_guess && !ovf && !(DBG && (a.debug_skip & 2))) {
-            constexpr int MPLG = T / THREADS;
-            bool gv = true;
-#pragma unroll
-            for (int j = 0; j < PKD; ++j)
-                if (j < a.nk && !kvalid(guess[j])) gv = false;
-            if (gv) {                                    // uniform: every thread loaded the same words
-                if (threadIdx.x < PK) s_nex[threadIdx.x] = 0;
-                if (threadIdx.x == 0) s_more = 0;
-                __syncthreads();
-#pragma unroll 2
-                for (int q = 0; q < MPLG; ++q) {
-                    K kk[PKD];
-                    slot_keys(q * THREADS + threadIdx.x, kk);
-#pragma unroll
-                    for (int j = 0; j < PKD; ++j) {
-                        if (j < a.nk && kvalid(kk[j]) && kbetter(kk[j], guess[j])) {
-                            const uint32_t pos = atomicAdd(&s_nex[j], 1u);
-                            if (pos < (uint32_t)EXCAP) kstore(kk[j], &s_exw[j][pos], &s_exy[0][WIDE ? pos : 0]);
-                            else s_more = 1;
-                        }
-                    }
-                }
-                __syncthreads();
-                bool ok = s_more == 0;
-#pragma unroll
-                for (int j = 0; j < PKD; ++j)
-                    if (j < a.nk && s_nex[j] < (uint32_t)a.k) ok = false;
-#ifdef OTTO_PHASE_PROF
-                if (threadIdx.x == 0) { ph[8]++; if (ok) ph[9]++; else if (s_more) ph[11]++; else ph[10]++; }
-#endif
-                if (ok) {
-                    if (wid < a.nk && wid < PKD) {
-                        const uint32_t n = s_nex[wid];
-                        K cand;
-                        kclear(cand);
-                        if (lane < n) kload(cand, s_exw[wid][lane], s_exy[0][WIDE ? lane : 0]);
-                        wave_bitonic_sort_desc(cand);
-                        emit(wid, cand);
-                        if (n >= 32u && lane == 31u) {
-                            ktau_store(cand, a.tau_w, a.tau_y, (size_t)wid * a.n_aids + x);
-                        }
-                    }
-                    fast_done = true;
-                }
-                __syncthreads();                         // lists are reused by the two-pass path / the next item
-            }
-        }
         OTTO_PH(7);
         if (fast_done || (DBG && (a.debug_skip & 2))) {
         } else if (ovf) {
@@ -2061,92 +1956,221 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
 #pragma unroll
                 for (int j = 0; j < PKD; ++j)
                     if (j < a.nk) emit(j, bests[j]);
-            } else {
-                // ---- block-wide: ONE sort per kind. P1 every lane: lane-best to LDS.
-                //      P2 wave j: top-k of the THREADS lane-bests, publish the k-th as threshold.
-                //      P3 every lane: the (rare) other candidates above the threshold go to a small list.
-                //      P4 wave j: insert them, emit. P3/P4 repeat only if the list overflowed. -------------
+            }
+            }
+        }
+        } else {
+        // ================= multi-wave bins: walk the dense list of occupied slots =================
+        const uint32_t nocc = s_nocc;
+        const bool dense = nocc <= (uint32_t)OCAP;                    // else: more distinct keys than the list holds
+        if (ovf) {
+            // LDS table full: ask the host to redo this aid with twice the partitions
+            if (threadIdx.x == 0) {
+                a.flag[x] = 1;
+                a.boost[x] = (uint8_t)(lgR - l_log2r(a.cnt64[x], 0, a.l_cap, a.allow_packed) + 1);
+                atomicAdd(a.ovf_count, 1u);
+            }
+        } else if (!(DBG && (a.debug_skip & 2))) {
+            constexpr int MPL = T / THREADS;
+            const int nit = dense ? (int)((nocc + THREADS - 1) / THREADS) : MPL;     // entries per lane (uniform)
+            auto slot_at = [&](int q) -> int {                                        // q-th entry of this lane, -1: none
+                const uint32_t idx = (uint32_t)q * THREADS + threadIdx.x;
+                if (!dense) return (int)idx;
+                return idx < nocc ? (int)s_occ[NW > 1 ? idx : 0] : -1;
+            };
+            // key of ONE kind (weight vector c0, c1, c2 of that kind, hoisted by the caller) of table slot i
+            auto slot_key1 = [&](int i, uint32_t c0, uint32_t c1, uint32_t c2) {
+                uint32_t y, v0, v1, v2;
+                if (PACKED) {
+                    const uint64_t v = s_tab[PACKED ? i : 0];
+                    y = v == TAB_EMPTY ? KEY_EMPTY : (uint32_t)(v >> 36);
+                    v0 = (uint32_t)v & 0xFFFu; v1 = (uint32_t)(v >> 12) & 0xFFFu; v2 = (uint32_t)(v >> 24) & 0xFFFu;
+                } else {
+                    y = s_key[PACKED ? 0 : i];
+                    v0 = s_v[0][PACKED ? 0 : i]; v1 = s_v[1][PACKED ? 0 : i]; v2 = s_v[2][PACKED ? 0 : i];
+                }
+                uint64_t uw = 0, qw = 0;
+                if (y != KEY_EMPTY) {
+                    if (GROUP == OTTO_COVIS_GROUP_TIME) qw = 65536ull * v0 + (((uint64_t)v2 << 32) | v1);
+                    else if (PACKED) uw = v0 * c0 + v1 * c1 + v2 * c2;
+                    else uw = (uint64_t)v0 * c0 + (uint64_t)v1 * c1 + (uint64_t)v2 * c2;
+                }
+                K r;
+                kmake(r, uw, qw, y);
+                return r;
+            };
+            // rank r of kind j -> output row (unpartitioned aid) or this partition's partial list; nv valid keys in the wave
+            auto emit_ranked = [&](int j, K key, uint32_t rank, int nv) {
+                const bool put = kvalid(key) && rank < (uint32_t)a.k;
+                if (lgR == 0) {
+                    const size_t o = ((size_t)(a.kind_base + j) * a.n_aids + x) * (size_t)a.k + rank;
+                    if (put) { a.out_y[o] = kaid(key); a.out_w[o] = kweight(key); }
+                    if (lane == 0) a.out_n[(size_t)(a.kind_base + j) * a.n_aids + x] = nv < a.k ? nv : a.k;
+                } else {
+                    const size_t base = ((size_t)it * a.nk + j) * (size_t)a.k;
+                    if (put) kstore(key, &a.part_w[base + rank], &a.part_y[base + rank]);
+                    if ((int)lane < a.k && (int)lane >= nv) { K z; kclear(z); kstore(z, &a.part_w[base + lane], &a.part_y[base + lane]); }
+                }
+            };
+            // Kind j from its candidate list s_exw[j][0, n), n <= 64 (every key at or above the threshold): rank = number
+            // of better candidates, read back with uniform addresses -- no sorting network, every iteration independent.
+            // Keys are distinct (one per aid_y), so the ranks are a permutation.
+            auto finish_list = [&](int j, uint32_t n, bool store_tau) {
+                K key;
+                kclear(key);
+                if (lane < n) kload(key, s_exw[j][lane], s_exy[0][WIDE ? lane : 0]);
+                uint32_t rank = 0;
+#pragma unroll 4
+                for (uint32_t i = 0; i < n; ++i) {
+                    K o;
+                    kload(o, s_exw[j][i], s_exy[0][WIDE ? i : 0]);
+                    rank += kbetter(o, key) ? 1u : 0u;
+                }
+                emit_ranked(j, key, rank, (int)n);
+                if (store_tau && n >= 32u && kvalid(key) && rank == 31u) ktau_store(key, a.tau_w, a.tau_y, (size_t)j * a.n_aids + x);
+            };
+            // exact top-k of kind j by ONE wave (two walks over the list / table): only when a candidate list overflowed
+            auto wave_exact_topk = [&](int j) {
+                const int total = dense ? (int)nocc : T;
+                const uint32_t c0 = a.coef[j][0], c1 = a.coef[j][1], c2 = a.coef[j][2];
+                K lb;
+                kclear(lb);
+                int bi = -1;
+                for (int i = (int)lane; i < total; i += 64) {
+                    const int sl = dense ? (int)s_occ[NW > 1 ? i : 0] : i;
+                    const K key = slot_key1(sl, c0, c1, c2);
+                    if (kbetter(key, lb)) { lb = key; bi = i; }
+                }
+                K best = lb;
+                wave_bitonic_sort_desc(best);
+                for (int i0 = 0; i0 < total; i0 += 64) {
+                    const int i = i0 + (int)lane;
+                    K key;
+                    kclear(key);
+                    if (i < total && i != bi) key = slot_key1(dense ? (int)s_occ[NW > 1 ? i : 0] : i, c0, c1, c2);
+                    wave_topk_push(best, key, a.k);
+                }
+                emit(j, best);
+            };
+            auto append = [&](int j, K key) {
+                const uint32_t pos = atomicAdd(&s_nex[j], 1u);
+                if (pos < (uint32_t)EXCAP) kstore(key, &s_exw[j][pos], &s_exy[0][WIDE ? pos : 0]);
+                else s_more = 1;
+            };
+
+            // ---- partitions of a heavy aid whose sibling left a threshold guess: ONE walk collects every key above the
+            //      guess; at least k per kind and no overflow: the ranked lists are the exact top-k ----
+            bool fast_done = false;
+            bool gv = use_guess;
+#pragma unroll
+            for (int j = 0; j < PKD; ++j)
+                if (j < a.nk && !kvalid(guess[j])) gv = false;
+            if (gv) {                                    // uniform: every thread loaded the same words
+                if (threadIdx.x < PK) s_nex[threadIdx.x] = 0;
+                if (threadIdx.x == 0) s_more = 0;
+                __syncthreads();
+                for (int q = 0; q < nit; ++q) {
+                    const int sl = slot_at(q);
+                    if (sl < 0) continue;
+                    K kk[PKD];
+                    slot_keys(sl, kk);
+#pragma unroll
+                    for (int j = 0; j < PKD; ++j)
+                        if (j < a.nk && kvalid(kk[j]) && kbetter(kk[j], guess[j])) append(j, kk[j]);
+                }
+                __syncthreads();
+                bool ok = s_more == 0;
 #pragma unroll
                 for (int j = 0; j < PKD; ++j)
-                    if (j < a.nk) kstore(lb[j], &s_lbw[j][threadIdx.x], &s_lby[0][WIDE ? threadIdx.x : 0]);
+                    if (j < a.nk && s_nex[j] < (uint32_t)a.k) ok = false;
+#ifdef OTTO_PHASE_PROF
+                if (threadIdx.x == 0) { ph[8]++; if (ok) ph[9]++; else if (s_more) ph[11]++; else ph[10]++; }
+#endif
+                if (ok) {
+                    if (wid < a.nk && wid < PKD) finish_list(wid, s_nex[wid], true);
+                    fast_done = true;
+                }
+                __syncthreads();                         // lists are reused by the two-pass path / the next item
+            }
+            OTTO_PH(7);
+            if (!fast_done) {
+                // ---- P1 every lane: its best key per kind -> the key's SLOT to LDS. P2 wave j: best of each group of NW
+                //      lanes, one 64-lane sort, k-th = threshold of kind j (a lower bound of the k-th best key: the group
+                //      bests are a subset). P3 every lane: keys at or above the threshold -> candidate list of the kind
+                //      (about k of them). P4 wave j: rank the list. ----
+                K lb[PKD];
+                int bi[PKD];
+#pragma unroll
+                for (int j = 0; j < PKD; ++j) { kclear(lb[j]); bi[j] = 0xFFFF; }
+                for (int q = 0; q < nit; ++q) {
+                    const int sl = slot_at(q);
+                    if (sl < 0) continue;
+                    K kk[PKD];
+                    slot_keys(sl, kk);
+#pragma unroll
+                    for (int j = 0; j < PKD; ++j)
+                        if (kbetter(kk[j], lb[j])) { lb[j] = kk[j]; bi[j] = sl; }
+                }
+#pragma unroll
+                for (int j = 0; j < PKD; ++j)
+                    if (j < a.nk) s_lbi[j][NW > 1 ? threadIdx.x : 0] = (uint16_t)bi[j];
                 if (threadIdx.x < PK) s_nex[threadIdx.x] = 0;
                 if (threadIdx.x == 0) s_more = 0;
                 __syncthreads();
                 OTTO_PH(4);
-                K best;
-                kclear(best);
-                const bool merger = wid < a.nk && wid < PKD;      // wave j finishes kind j (nk <= PK <= NW)
-                if (merger) {
-                    K lbs[NW];
+                if (wid < a.nk && wid < PKD) {
+                    K gb;
+                    kclear(gb);
+                    const uint32_t c0 = a.coef[wid][0], c1 = a.coef[wid][1], c2 = a.coef[wid][2];
 #pragma unroll
-                    for (int q = 0; q < NW; ++q)
-                        kload(lbs[q], s_lbw[wid][q * 64 + lane], s_lby[0][WIDE ? q * 64 + lane : 0]);
-                    // with threshold guessing on, keep the 32 best lane-bests sorted: lane 31 ends up a lower bound of the
-                    // partition's 32nd best key = the guess for the aid's other partitions
-                    wave_topk_select<NW, K>(lbs, use_guess ? MAX_K : a.k, best);
-                    const K thr = kshfl(best, a.k - 1);
+                    for (int q = 0; q < NW; ++q) {
+                        const uint32_t sl = s_lbi[wid][NW > 1 ? q * 64 + lane : 0];
+                        if (sl != 0xFFFFu) {
+                            const K o = slot_key1((int)sl, c0, c1, c2);
+                            if (kbetter(o, gb)) gb = o;
+                        }
+                    }
+                    wave_bitonic_sort_desc(gb);
+                    const K thr = kshfl(gb, a.k - 1);
                     if (lane == 0) kstore(thr, &s_thrw[wid], &s_thry[wid]);
+                    // lane 31: a lower bound of the partition's 32nd best key = the guess for the aid's other partitions
+                    if (use_guess && lane == 31u && kvalid(gb)) ktau_store(gb, a.tau_w, a.tau_y, (size_t)wid * a.n_aids + x);
                 }
-                for (;;) {
-                    OTTO_PH(5);
-                    __syncthreads();
-                    K thr[PKD];
+                OTTO_PH(5);
+                __syncthreads();
+                K thr[PKD];
 #pragma unroll
-                    for (int j = 0; j < PKD; ++j) kload(thr[j], s_thrw[j], s_thry[j]);
-                    // only the non-empty slots: the wave runs as many rounds as its fullest lane has keys
-                    uint32_t rem = nonempty;
-                    while (__ballot(rem != 0) != 0) {
-                        if (rem != 0) {
-                            const int q = __builtin_ctz(rem);
-                            rem &= rem - 1u;
-                            K kk[PKD];
-                            slot_keys(q * THREADS + threadIdx.x, kk);
+                for (int j = 0; j < PKD; ++j) kload(thr[j], s_thrw[j], s_thry[j]);
+                for (int q = 0; q < nit; ++q) {
+                    const int sl = slot_at(q);
+                    if (sl < 0) continue;
+                    K kk[PKD];
+                    slot_keys(sl, kk);
 #pragma unroll
-                            for (int j = 0; j < PKD; ++j) {
-                                if (j < a.nk && !((done[j] >> q) & 1u) && kvalid(kk[j]) && kbetter(kk[j], thr[j])) {
-                                    const uint32_t pos = atomicAdd(&s_nex[j], 1u);
-                                    if (pos < (uint32_t)EXCAP) {
-                                        kstore(kk[j], &s_exw[j][pos], &s_exy[0][WIDE ? pos : 0]);
-                                        done[j] |= 1u << q;
-                                    } else {
-                                        s_more = 1;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    __syncthreads();
-                    OTTO_PH(6);
-                    const bool more = s_more != 0;
-                    if (merger) {
-                        const uint32_t n = s_nex[wid] < (uint32_t)EXCAP ? s_nex[wid] : (uint32_t)EXCAP;
-                        for (uint32_t c0 = 0; c0 < n; c0 += 64) {
-                            K cand;
-                            kclear(cand);
-                            if (c0 + lane < n) kload(cand, s_exw[wid][c0 + lane], s_exy[0][WIDE ? c0 + lane : 0]);
-                            wave_topk_push(best, cand, a.k);
-                        }
-                        if (more) {
-                            const K thr2 = kshfl(best, a.k - 1);
-                            if (lane == 0) kstore(thr2, &s_thrw[wid], &s_thry[wid]);
-                        }
-                    }
-                    if (!more) break;
-                    __syncthreads();
-                    if (threadIdx.x < PK) s_nex[threadIdx.x] = 0;
-                    if (threadIdx.x == 0) s_more = 0;
+                    for (int j = 0; j < PKD; ++j)
+                        if (j < a.nk && kvalid(kk[j]) && !kbetter(thr[j], kk[j])) append(j, kk[j]);
                 }
-                if (merger) {
-                    emit(wid, best);
-                    if (use_guess && lane == 31u && kvalid(best)) {
-                        ktau_store(best, a.tau_w, a.tau_y, (size_t)wid * a.n_aids + x);
-                    }
+                __syncthreads();
+                OTTO_PH(6);
+                if (wid < a.nk && wid < PKD) {
+                    if (s_more) wave_exact_topk(wid);
+                    else finish_list(wid, s_nex[wid] < (uint32_t)EXCAP ? s_nex[wid] : (uint32_t)EXCAP, false);
                 }
                 OTTO_PH(7);
             }
+        }
+        // ---- clear the table for the next item: through the list when it is complete ----
+        __syncthreads();
+        if (!(DBG && (a.debug_skip & 4))) {
+            if (dense) {
+                for (uint32_t idx = threadIdx.x; idx < nocc; idx += THREADS) clear_slot((int)s_occ[NW > 1 ? idx : 0]);
+            } else {
+                clear_table();
             }
         }
-        }   // !BOUND
+        if (threadIdx.x == 0) { s_nocc = 0; s_ovf = 0; }
+        }   // multi-wave bins
+
         // ---- hand the prefetched next item over ----
         if (DYNAMIC) {
             __syncthreads();                       // every thread is done with s_cur's consumers and the table
@@ -2162,7 +2186,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     }
 #ifdef OTTO_PHASE_PROF
     if (threadIdx.x == 0 && a.prof)
-        for (int i = 0; i < 12; ++i) atomicAdd(&a.prof[i], ph[i]);
+        for (int i = 0; i < 16; ++i) atomicAdd(&a.prof[i], ph[i]);
 #endif
 }
 
@@ -2806,17 +2830,17 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
     // diagnostic build only: per-launch phase shares (shader-clock ticks of thread 0 of every workgroup) + wall time
     static unsigned long long* d_prof = nullptr;
     static hipEvent_t pe0 = nullptr, pe1 = nullptr;
-    if (!d_prof) { OTTO_HIP(hipMalloc(&d_prof, 96)); OTTO_HIP(hipEventCreate(&pe0)); OTTO_HIP(hipEventCreate(&pe1)); }
+    if (!d_prof) { OTTO_HIP(hipMalloc(&d_prof, 128)); OTTO_HIP(hipEventCreate(&pe0)); OTTO_HIP(hipEventCreate(&pe1)); }
     a.prof = d_prof;
-    auto prof_begin = [&]() { (void)hipMemsetAsync(d_prof, 0, 96, s); (void)hipEventRecord(pe0, s); };
+    auto prof_begin = [&]() { (void)hipMemsetAsync(d_prof, 0, 128, s); (void)hipEventRecord(pe0, s); };
     auto prof_end = [&](const char* tag, uint32_t n_work) {
-        unsigned long long h[12];
-        (void)hipEventRecord(pe1, s); (void)hipStreamSynchronize(s); (void)hipMemcpy(h, d_prof, 96, hipMemcpyDeviceToHost);
+        unsigned long long h[16];
+        (void)hipEventRecord(pe1, s); (void)hipStreamSynchronize(s); (void)hipMemcpy(h, d_prof, 128, hipMemcpyDeviceToHost);
         float ms = 0.f; (void)hipEventElapsedTime(&ms, pe0, pe1);
         unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += h[i];
         fprintf(stderr, "[phase-prof] %s items %u  %.3f ms:", tag, n_work, ms);
         for (int i = 0; i < 8; ++i) fprintf(stderr, " p%d %.1f%%", i, tot ? 100.0 * h[i] / tot : 0.0);
-        fprintf(stderr, "  (ticks %llu) guess: tried %llu ok %llu toofew %llu overflow %llu\n", tot, h[8], h[9], h[10], h[11]);
+        fprintf(stderr, "  (ticks %llu) guess: tried %llu ok %llu toofew %llu overflow %llu | two-pass %llu: cand<=64 %llu <=256 %llu exact-fallback %llu\n", tot, h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
     };
 #else
     auto prof_begin = [&]() {};
