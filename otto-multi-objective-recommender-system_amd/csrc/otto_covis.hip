@@ -1322,8 +1322,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     // walk ceil(occupied / THREADS) entries per lane instead of T / THREADS slots (the tables run 15 - 40 % full), and the
     // table is cleared through the list. More distinct keys than OCAP: the passes fall back to walking the table.
     constexpr int OCAP = NW == 1 ? 1 : (LOG2T == 12 ? 2048 : (LOG2T == 14 ? 12288 : (THREADS == 512 ? 5632 : 6144)));
+    constexpr int RCAP = OCAP / NW;         // one list region per wave: appended to with a wave-private counter (no atomics)
     __shared__ uint16_t s_occ[OCAP];
-    __shared__ uint32_t s_nocc;
+    __shared__ uint32_t s_wcnt[NW];         // keys each wave entered into the table (published after the insert phase)
     __shared__ uint16_t s_lbi[NW > 1 ? PKD : 1][NW > 1 ? THREADS : 1];         // slot of every lane's best key per kind (0xFFFF: none)
     __shared__ uint64_t s_exw[(NW > 1 || BOUND) ? PKD : 1][(NW > 1 || BOUND) ? EXCAP : 1];   // candidates above the threshold / rank broadcast
     __shared__ uint16_t s_cand[BOUND ? CCAP : 1];                               // BOUND: slots of the candidates
@@ -1336,6 +1337,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     constexpr int LISTCAP = BOUND ? S_CAP : 256;
     __shared__ uint16_t s_list[NW == 1 ? LISTCAP : 1];                         // one-wave bins: compacted valid slots
     __shared__ ItemDesc s_cur;
+    __shared__ ItemDesc s_nxt;                                                // the item after s_cur (for the record prefetch)
 
     const int wid = threadIdx.x >> 6;
     const unsigned lane = lane_id();
@@ -1407,8 +1409,28 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     };
     if (NW > 1) {
         clear_table();
-        if (threadIdx.x == 0) { s_nocc = 0; s_ovf = 0; }
+        if (threadIdx.x == 0) s_ovf = 0;
     }
+    // Records of a bucketed heavy-aid partition per thread and round trip: a whole partition (wide: l_cap = 6 * 1024,
+    // packed: 12 * 1024) in one. PREF: the first round of the NEXT item is requested during the tail of the current
+    // item's top-k (after its last walk over the table), so a one-workgroup-per-CU kernel no longer sits through the whole
+    // HBM round trip + the CU's ingest time (48 KB at ~24 GB/s) between two items.
+    constexpr int BU = GROUP == OTTO_COVIS_GROUP_TIME ? 4 : ((PACKED && THREADS == L_THREADS) ? 12 : 6);
+    constexpr bool PREF = THREADS == L_THREADS && GROUP != OTTO_COVIS_GROUP_TIME;   // the kernels that read partition buckets
+    uint32_t pre[PREF ? BU : 1];
+    bool pre_valid = false;                // uniform: pre[] holds the first round of the item that becomes `cur` next
+    auto prefetch_next = [&]() {
+        if (!PREF) return;
+        const uint64_t nitem = s_nxt.item;
+        pre_valid = s_nxt.it != 0xFFFFFFFFu && (nitem >> 50) != 0 && a.pstart != nullptr;
+        if (!pre_valid) return;
+        const uint64_t ps = s_nxt.ps, pe = s_nxt.pe;
+#pragma unroll
+        for (int u = 0; u < (PREF ? BU : 1); ++u) {
+            const uint64_t i = ps + threadIdx.x + (uint64_t)u * THREADS;
+            pre[u] = i < pe ? a.prec[i] : KEY_EMPTY;
+        }
+    };
 
     for (;;) {
         if (DYNAMIC) {
@@ -1421,6 +1443,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         // stage 1 of the next item
         if (DYNAMIC) {
             if (threadIdx.x == 0) fetch_item(idx_next, nx);
+#ifdef OTTO_PHASE_PROF
+            if (threadIdx.x == 0) { const unsigned long long _t = clock64(); ph[13] += _t - ph_t; }   // part of p1: next item's dependent index -> item loads
+#endif
         } else {
             fetch_item(sidx + gridDim.x, nx);
         }
@@ -1457,35 +1482,35 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         // round trips in flight per lane instead of one), then hits (key already there: add) and misses (next probe) are
         // resolved. `e` = time extra (GROUP_TIME only). CAS first, no read: a new key (most records) costs ONE LDS
         // operation in the packed layout -- it goes in together with its first count.
-        // a key entered the table at `slot`: append the slot to the dense list. Wave-aggregated: one counter bump per wave
-        // and insert round (every lane of the wave calls this together); note_new1 is the per-lane form of the probe loops
+        auto probe_step = [&](uint32_t y) -> uint32_t { return (((y * 0x85EBCA6Bu) ^ (y >> 7)) * 0xC2B2AE35u >> (32 - LOG2T)) | 1u; };
+        // a key entered the table at `slot`: append the slot to this wave's region of the dense list. The position comes from
+        // a wave-private counter and the ballot rank: no LDS atomic, no round trip (every lane of the wave calls this
+        // together; lanes that claim a slot later, inside a probe loop, report it after the loop through the same call)
+        uint32_t wc = 0;
         auto note_new = [&](bool isnew, uint32_t slot) {
             if (NW == 1) return;
             const uint64_t m = __ballot(isnew);
             if (m == 0) return;
-            const int leader = __ffsll((unsigned long long)m) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(&s_nocc, (uint32_t)__popcll(m));
-            base = (uint32_t)__shfl((int)base, leader, 64);
-            const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (isnew && pos < (uint32_t)OCAP) s_occ[NW > 1 ? pos : 0] = (uint16_t)slot;
+            const uint32_t pos = wc + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (isnew && pos < (uint32_t)RCAP) s_occ[NW > 1 ? wid * RCAP + pos : 0] = (uint16_t)slot;
+            wc += (uint32_t)__popcll(m);
         };
-        auto note_new1 = [&](uint32_t slot) {
-            if (NW == 1) return;
-            const uint32_t pos = atomicAdd(&s_nocc, 1u);
-            if (pos < (uint32_t)OCAP) s_occ[NW > 1 ? pos : 0] = (uint16_t)slot;
-        };
-        auto probe_on = [&](uint32_t y, uint32_t slot, unsigned long long add, unsigned long long fresh) {   // packed: slots after the first
+        // Double hashing: the probe step is a second hash of the key (odd: every slot is visited in T probes). Linear probing
+        // builds clusters, and a wave waits for its longest chain: every probe is a dependent LDS round trip.
+        // returns the slot it claimed for a NEW key, else 0xFFFFFFFF
+        auto probe_on = [&](uint32_t y, uint32_t slot, unsigned long long add, unsigned long long fresh) -> uint32_t {   // packed: slots after the first
+            const uint32_t step = probe_step(y);
             for (int probe = 1; probe < T; ++probe) {
-                slot = (slot + 1) & (T - 1);
+                slot = (slot + step) & (T - 1);
                 const unsigned long long old = atomicCAS((unsigned long long*)&s_tab[PACKED ? slot : 0], (unsigned long long)TAB_EMPTY, fresh | add);
-                if (old == TAB_EMPTY) { note_new1(slot); return; }
+                if (old == TAB_EMPTY) return slot;
                 if ((uint32_t)(old >> 36) == y) {
                     atomicAdd((unsigned long long*)&s_tab[PACKED ? slot : 0], add);
-                    return;
+                    return 0xFFFFFFFFu;
                 }
             }
             s_ovf = 1;
+            return 0xFFFFFFFFu;
         };
         auto wide_add = [&](uint32_t rc, uint32_t found, uint32_t e) {
             if (GROUP == OTTO_COVIS_GROUP_TIME) {
@@ -1552,11 +1577,15 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                     }
 #pragma unroll
                     for (int q = 0; q < CH; ++q) {
-                        if (oldhi[q] == 0xFFFFFFFFu) continue;    // not a record, or a new key that went in with its first count
+                        // oldhi == 0xFFFFFFFF: not a record, or a new key that went in with its first count
                         const uint32_t r = rc[c0 + q < N ? c0 + q : 0];
                         const uint32_t y = r & REC_AID_MASK, slot = rec_hash(r) >> (32 - LOG2T);
-                        if ((oldhi[q] >> 4) == y) atomicAdd((unsigned long long*)&s_tab[PACKED ? slot : 0], packed_add(r));
-                        else probe_on(y, slot, packed_add(r), (unsigned long long)y << 36);
+                        uint32_t late = 0xFFFFFFFFu;
+                        if (oldhi[q] != 0xFFFFFFFFu) {
+                            if ((oldhi[q] >> 4) == y) atomicAdd((unsigned long long*)&s_tab[PACKED ? slot : 0], packed_add(r));
+                            else late = probe_on(y, slot, packed_add(r), (unsigned long long)y << 36);
+                        }
+                        note_new(late != 0xFFFFFFFFu, late);
                     }
                     continue;
                 }
@@ -1570,19 +1599,23 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 }
 #pragma unroll
                 for (int q = 0; q < CH; ++q) {
-                    if (!ok[q]) continue;
                     const uint32_t r = rc[c0 + q < N ? c0 + q : 0];
                     const uint32_t y = r & REC_AID_MASK;
                     uint32_t sl = rec_hash(r) >> (32 - LOG2T);
-                    bool found = old[q] == KEY_EMPTY || old[q] == y;
-                    for (int probe = 1; !found && probe < T; ++probe) {
-                        sl = (sl + 1) & (T - 1);
-                        const uint32_t o2 = atomicCAS(&s_key[PACKED ? 0 : sl], KEY_EMPTY, y);
-                        if (o2 == KEY_EMPTY) note_new1(sl);
-                        found = o2 == KEY_EMPTY || o2 == y;
+                    uint32_t late = 0xFFFFFFFFu;
+                    if (ok[q]) {
+                        bool found = old[q] == KEY_EMPTY || old[q] == y;
+                        const uint32_t step = probe_step(y);
+                        for (int probe = 1; !found && probe < T; ++probe) {
+                            sl = (sl + step) & (T - 1);
+                            const uint32_t o2 = atomicCAS(&s_key[PACKED ? 0 : sl], KEY_EMPTY, y);
+                            if (o2 == KEY_EMPTY) late = sl;
+                            found = o2 == KEY_EMPTY || o2 == y;
+                        }
+                        if (!found) s_ovf = 1;
+                        else wide_add(r, sl, e[c0 + q < N ? c0 + q : 0]);
                     }
-                    if (!found) { s_ovf = 1; continue; }
-                    wide_add(r, sl, e[c0 + q < N ? c0 + q : 0]);
+                    note_new(late != 0xFFFFFFFFu, late);
                 }
             }
         };
@@ -1626,16 +1659,25 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         } else if (lgR > 0 && a.pstart) {
             // heavy aid, records already bucketed by hash partition: contiguous coalesced reads
             const uint64_t ps = cur.ps, pe = cur.pe;
-            // records per thread and round trip: a whole partition (wide: l_cap = 6 * 1024, packed: 12 * 1024) in one
-            constexpr int BU = GROUP == OTTO_COVIS_GROUP_TIME ? 4 : ((PACKED && THREADS == L_THREADS) ? 12 : 6);
+            bool first = true;
             for (uint64_t i0 = ps + threadIdx.x; i0 < pe; i0 += BU * THREADS) {
                 uint32_t rc[BU], e[BU];
+                if (PREF && first && pre_valid) {
 #pragma unroll
-                for (int u = 0; u < BU; ++u) {
-                    const uint64_t i = i0 + (uint64_t)u * THREADS;
-                    rc[u] = i < pe ? a.prec[i] : KEY_EMPTY;
-                    e[u] = (GROUP == OTTO_COVIS_GROUP_TIME && i < pe) ? a.ptw[i] : 0u;
+                    for (int u = 0; u < BU; ++u) { rc[u] = pre[PREF ? u : 0]; e[u] = 0u; }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < BU; ++u) {
+                        const uint64_t i = i0 + (uint64_t)u * THREADS;
+                        rc[u] = i < pe ? a.prec[i] : KEY_EMPTY;
+                        e[u] = (GROUP == OTTO_COVIS_GROUP_TIME && i < pe) ? a.ptw[i] : 0u;
+                    }
                 }
+                first = false;
+#ifdef OTTO_PHASE_PROF
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (threadIdx.x == 0) { const unsigned long long _t = clock64(); ph[12] += _t - ph_t; ph[2] -= _t - ph_t; }   // p2 = inserts only; ph[12] = wait for the records
+#endif
                 bool okb[BU];
 #pragma unroll
                 for (int u = 0; u < BU; ++u) okb[u] = rc[u] != KEY_EMPTY;
@@ -1655,6 +1697,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 insert_batch(std::integral_constant<int, GU>{}, rc, okb, e);
             });
         }
+        if (NW > 1 && lane == 0) s_wcnt[NW > 1 ? wid : 0] = wc;
+        pre_valid = false;                     // consumed (or not applicable); set again by prefetch_next below
         // stage 2 of the next item (its item word has long arrived)
         if (!DYNAMIC || threadIdx.x == 0) fetch_ranges(nx);
         OTTO_PH(2);
@@ -1961,8 +2005,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         }
         } else {
         // ================= multi-wave bins: walk the dense list of occupied slots =================
-        const uint32_t nocc = s_nocc;
-        const bool dense = nocc <= (uint32_t)OCAP;                    // else: more distinct keys than the list holds
+        const uint32_t nocc = s_wcnt[NW > 1 ? wid : 0];               // this wave's region: the keys IT entered
+        bool dense = true;                                            // else: some wave entered more keys than its region holds
+#pragma unroll
+        for (int w = 0; w < NW; ++w) dense = dense && s_wcnt[NW > 1 ? w : 0] <= (uint32_t)RCAP;
         if (ovf) {
             // LDS table full: ask the host to redo this aid with twice the partitions
             if (threadIdx.x == 0) {
@@ -1972,11 +2018,11 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             }
         } else if (!(DBG && (a.debug_skip & 2))) {
             constexpr int MPL = T / THREADS;
-            const int nit = dense ? (int)((nocc + THREADS - 1) / THREADS) : MPL;     // entries per lane (uniform)
+            const int nit = dense ? (int)((nocc + 63u) / 64u) : MPL;                  // entries per lane (uniform in the wave)
             auto slot_at = [&](int q) -> int {                                        // q-th entry of this lane, -1: none
-                const uint32_t idx = (uint32_t)q * THREADS + threadIdx.x;
-                if (!dense) return (int)idx;
-                return idx < nocc ? (int)s_occ[NW > 1 ? idx : 0] : -1;
+                if (!dense) return q * THREADS + (int)threadIdx.x;
+                const uint32_t idx = (uint32_t)q * 64u + lane;
+                return idx < nocc ? (int)s_occ[NW > 1 ? wid * RCAP + idx : 0] : -1;
             };
             // key of ONE kind (weight vector c0, c1, c2 of that kind, hoisted by the caller) of table slot i
             auto slot_key1 = [&](int i, uint32_t c0, uint32_t c1, uint32_t c2) {
@@ -2031,24 +2077,34 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             };
             // exact top-k of kind j by ONE wave (two walks over the list / table): only when a candidate list overflowed
             auto wave_exact_topk = [&](int j) {
-                const int total = dense ? (int)nocc : T;
                 const uint32_t c0 = a.coef[j][0], c1 = a.coef[j][1], c2 = a.coef[j][2];
+                // entry e of the walk: region by region (dense) or slot by slot
+                const int nreg = dense ? NW : 1;
                 K lb;
                 kclear(lb);
                 int bi = -1;
-                for (int i = (int)lane; i < total; i += 64) {
-                    const int sl = dense ? (int)s_occ[NW > 1 ? i : 0] : i;
-                    const K key = slot_key1(sl, c0, c1, c2);
-                    if (kbetter(key, lb)) { lb = key; bi = i; }
+                for (int w = 0; w < nreg; ++w) {
+                    const int total = dense ? (int)s_wcnt[NW > 1 ? w : 0] : T;
+                    for (int i = (int)lane; i < total; i += 64) {
+                        const int sl = dense ? (int)s_occ[NW > 1 ? w * RCAP + i : 0] : i;
+                        const K key = slot_key1(sl, c0, c1, c2);
+                        if (kbetter(key, lb)) { lb = key; bi = sl; }
+                    }
                 }
                 K best = lb;
                 wave_bitonic_sort_desc(best);
-                for (int i0 = 0; i0 < total; i0 += 64) {
-                    const int i = i0 + (int)lane;
-                    K key;
-                    kclear(key);
-                    if (i < total && i != bi) key = slot_key1(dense ? (int)s_occ[NW > 1 ? i : 0] : i, c0, c1, c2);
-                    wave_topk_push(best, key, a.k);
+                for (int w = 0; w < nreg; ++w) {
+                    const int total = dense ? (int)s_wcnt[NW > 1 ? w : 0] : T;
+                    for (int i0 = 0; i0 < total; i0 += 64) {
+                        const int i = i0 + (int)lane;
+                        K key;
+                        kclear(key);
+                        if (i < total) {
+                            const int sl = dense ? (int)s_occ[NW > 1 ? w * RCAP + i : 0] : i;
+                            if (sl != bi) key = slot_key1(sl, c0, c1, c2);
+                        }
+                        wave_topk_push(best, key, a.k);
+                    }
                 }
                 emit(j, best);
             };
@@ -2061,6 +2117,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             // ---- partitions of a heavy aid whose sibling left a threshold guess: ONE walk collects every key above the
             //      guess; at least k per kind and no overflow: the ranked lists are the exact top-k ----
             bool fast_done = false;
+            bool pre_issued = false;
             bool gv = use_guess;
 #pragma unroll
             for (int j = 0; j < PKD; ++j)
@@ -2078,7 +2135,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                     for (int j = 0; j < PKD; ++j)
                         if (j < a.nk && kvalid(kk[j]) && kbetter(kk[j], guess[j])) append(j, kk[j]);
                 }
+                if (PREF && threadIdx.x == 0) s_nxt = nx;
                 __syncthreads();
+                prefetch_next();                         // last walk over the table done: request the next item's records
+                pre_issued = true;
                 bool ok = s_more == 0;
 #pragma unroll
                 for (int j = 0; j < PKD; ++j)
@@ -2150,7 +2210,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                     for (int j = 0; j < PKD; ++j)
                         if (j < a.nk && kvalid(kk[j]) && !kbetter(thr[j], kk[j])) append(j, kk[j]);
                 }
+                if (PREF && !pre_issued && threadIdx.x == 0) s_nxt = nx;
                 __syncthreads();
+                if (!pre_issued) prefetch_next();
                 OTTO_PH(6);
                 if (wid < a.nk && wid < PKD) {
                     if (s_more) wave_exact_topk(wid);
@@ -2163,12 +2225,12 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         __syncthreads();
         if (!(DBG && (a.debug_skip & 4))) {
             if (dense) {
-                for (uint32_t idx = threadIdx.x; idx < nocc; idx += THREADS) clear_slot((int)s_occ[NW > 1 ? idx : 0]);
+                for (uint32_t idx = lane; idx < nocc; idx += 64u) clear_slot((int)s_occ[NW > 1 ? wid * RCAP + idx : 0]);
             } else {
                 clear_table();
             }
         }
-        if (threadIdx.x == 0) { s_nocc = 0; s_ovf = 0; }
+        if (threadIdx.x == 0) s_ovf = 0;
         }   // multi-wave bins
 
         // ---- hand the prefetched next item over ----
@@ -2447,7 +2509,6 @@ struct otto_covis_ctx {
     int items_allow_packed = -1;   // layout rule the L item list was built with (-1: not built)
     DevBuf tau_w, tau_y;           // threshold guesses of partitioned heavy aids (per reduce pass)
     int guess = 1;                 // option "guess": single-pass top-k from a sibling partition's threshold
-    int ins_ch = 1;                // option "ins_ch": records per lane whose first-probe CAS is in flight together (1, 2, 4)
     DevBuf exp_run_pos, exp_rec_pos, exp_totals;
     uint64_t exp_n_runs[64] = {0}, exp_n_recs[64] = {0};
     int exp_planned = 0;
@@ -2807,10 +2868,6 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
     do {                                                                                               \
         if (GROUP == OTTO_COVIS_GROUP_TYPE && (args).debug_skip)                                       \
             k_reduce<__VA_ARGS__, 1, GROUP == OTTO_COVIS_GROUP_TYPE><<<grid, threads, 0, s>>>(args);   \
-        else if (c->ins_ch == 4)                                                                       \
-            k_reduce<__VA_ARGS__, 4, false><<<grid, threads, 0, s>>>(args);                            \
-        else if (c->ins_ch == 2)                                                                       \
-            k_reduce<__VA_ARGS__, 2, false><<<grid, threads, 0, s>>>(args);                            \
         else                                                                                           \
             k_reduce<__VA_ARGS__, 1, false><<<grid, threads, 0, s>>>(args);                            \
     } while (0)
@@ -2840,7 +2897,7 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
         unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += h[i];
         fprintf(stderr, "[phase-prof] %s items %u  %.3f ms:", tag, n_work, ms);
         for (int i = 0; i < 8; ++i) fprintf(stderr, " p%d %.1f%%", i, tot ? 100.0 * h[i] / tot : 0.0);
-        fprintf(stderr, "  (ticks %llu) guess: tried %llu ok %llu toofew %llu overflow %llu | two-pass %llu: cand<=64 %llu <=256 %llu exact-fallback %llu\n", tot, h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
+        fprintf(stderr, "  (ticks %llu) guess: tried %llu ok %llu toofew %llu overflow %llu | record wait (not in p2): %.1f%%, next-item fetch (in p1): %.1f%% of the ticks\n", tot, h[8], h[9], h[10], h[11], tot ? 100.0 * (double)h[12] / tot : 0.0, tot ? 100.0 * (double)h[13] / tot : 0.0);
     };
 #else
     auto prof_begin = [&]() {};
@@ -3039,11 +3096,6 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
     if (strcmp(name, "debug_skip") == 0) { c->debug_skip = (int)value; return 0; }   // timing diagnostics, results invalid
     if (strcmp(name, "packed_heavy") == 0) { c->packed_heavy = value != 0; c->index_valid = false; return 0; }
     if (strcmp(name, "bucket_index") == 0) { c->bucket_index = value != 0; return 0; }
-    if (strcmp(name, "ins_ch") == 0) {
-        OTTO_REQUIRE(value == 1 || value == 2 || value == 4, "ins_ch must be 1, 2 or 4");
-        c->ins_ch = (int)value;
-        return 0;
-    }
     if (strcmp(name, "guess") == 0) { c->guess = value != 0; return 0; }           // threshold guessing on/off (A/B)
     if (strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }           // fused in-order expansion on/off (A/B)
     if (strcmp(name, "fast_path") == 0) { c->fast_path = value != 0; return 0; }   // gap-free window kernel on/off (A/B)
