@@ -41,7 +41,11 @@ def parse():
     ap.add_argument('--sessions', type=int, default=14_571_582, help='sessions per rank (full OTTO = 14,571,582)')
     ap.add_argument('--k', type=int, default=20)
     ap.add_argument('--cpu-sessions', type=int, default=4_000_000, help='sample size of the cpu_baseline leg (0 = skip)')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='N > 1: weak = --sessions per rank (default); strong = ONE --sessions stream split by session chunk '
+                         '(BASELINE.json config 4: full OTTO across the GPUs)')
     ap.add_argument('--no-mf', action='store_true')
+    ap.add_argument('--no-dropin', action='store_true', help='skip the 7-kind drop-in build leg')
     ap.add_argument('--mf-rows', type=int, default=200_000_000)
     ap.add_argument('--mf-factors', type=int, default=64)
     return ap.parse_args()
@@ -69,20 +73,36 @@ def algorithmic_bytes(st, k, nk):
     return out
 
 
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'round1', 'traffic_v3.json')
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'round2', 'traffic.json')
 
 
-def pmc_traffic(substrings, full_otto):
-    """HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py under rocprofv3 --pmc FETCH_SIZE /
-    --pmc WRITE_SIZE, separate runs, calibrated: tools/pmc_summarize.py). They were taken on the full-OTTO workload,
-    so they are only attached when the bench runs that same workload; otherwise null."""
+def source_hash():
+    """sha256 over the kernel sources the traffic numbers belong to (csrc/*.hip, csrc/*.h, include/*.h)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, 'otto-multi-objective-recommender-system_amd', 'csrc')
+    for f in sorted(glob.glob(os.path.join(pkg, '*.hip')) + glob.glob(os.path.join(pkg, '*.h')) + glob.glob(os.path.join(ROOT, 'include', '*.h'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()
+
+
+def pmc_traffic(names, full_otto):
+    """HBM bytes per launch of the kernels `names` (template instantiations as the library reports them) from the committed
+    PMC passes (tools/pmc_traffic.py under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs, calibrated:
+    tools/pmc_summarize.py). PMC counters cannot be collected inside this run, so the file carries the hash of the kernel
+    sources it was measured on: a different hash (any kernel edit since) or a different workload gives null, never stale
+    numbers."""
     if not full_otto or not os.path.exists(TRAFFIC_FILE):
         return None
     try:
-        kernels = json.load(open(TRAFFIC_FILE))['kernels']
+        doc = json.load(open(TRAFFIC_FILE))
     except Exception:
         return None
-    tot = sum(v['traffic_bytes_per_launch'] for k, v in kernels.items() if any(sub in k for sub in substrings))
+    if doc.get('source_hash') != source_hash():
+        return None
+    tot = sum(v['traffic_bytes_per_launch'] for k, v in doc['kernels'].items() if any(n in k for n in names))
     return int(tot) if tot else None
 
 
@@ -126,6 +146,33 @@ def candidates_leg(data, dev, n_aids, train_sessions=3_000_000, sessions=1_800_0
     return out
 
 
+def dropin_leg(data, dev, n_aids, ts_min, ts_max, k, reps=2):
+    """What `covisitation/builder.py <mode>` runs on the device for the reference's consumers: the 7 matrix kinds
+    (time_weighted, three type-weighted, three filter kinds) of one event stream, top-k each: class-sorted pair-expand
+    (filter kinds), time channel, three reduce groups. Device-resident inputs, like the headline value."""
+    import torch
+    from otto_amd.covisitation.engine import CovisBuilder
+    from otto_amd.covisitation.spec import REFERENCE_KINDS
+    b = CovisBuilder(n_aids, kinds=REFERENCE_KINDS, ts_min=ts_min, ts_max=ts_max, device=dev)
+    tm = {}
+
+    def step():
+        b.reset()
+        b.feed(data['aid'], data['ts'], data['type'], data['sess_off'])
+        return b.finalize(k=k)
+    step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize(dev)
+    ms = 1e3 * (time.perf_counter() - t0) / reps
+    st = b.stats()
+    return {'ms_per_build': round(ms, 2), 'aid_pairs_per_s': round(st['pairs'] / (ms * 1e-3), 1), 'kinds': list(REFERENCE_KINDS), 'k': k,
+            'note': 'pairs counted once (the all-ones expansion feeds every kind); kernel_ms of the last reduce group below',
+            'kernel_ms_last_group': {n: round(v, 3) for n, v in b.timings().items()}, 'kernels': b.kernel_names()}
+
+
 def cpu_baseline(dev_data, n_sessions, k):
     """Time the CPU restatement (oracle/, kind 'port') on the first n_sessions of the same stream."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -140,7 +187,7 @@ def cpu_baseline(dev_data, n_sessions, k):
     except Exception:
         coc = None
     if coc is not None and coc.available():
-        cores = min(os.cpu_count() or 1, 64)
+        cores = os.cpu_count() or 1                      # every host core
         r = coc.covis_topk_c(aid, ts, typ, off, dev_data['n_aids'], BENCH_KINDS, k=k, threads=cores, rows=False)
         pairs, dt = r['P'], r['seconds_in_c']
         impl = f'oracle/covis_oracle.c (gcc -O3, OpenMP, {cores} threads)'
@@ -215,7 +262,18 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    data = generate_sessions_torch(a.sessions, n_aids=OTTO_N_AIDS, seed=42 + rank, device=dev)
+    if world > 1 and a.scaling == 'strong':
+        # ONE stream of --sessions sessions (same seed on every rank), rank r expands the session chunk [S r/W, S (r+1)/W)
+        full = generate_sessions_torch(a.sessions, n_aids=OTTO_N_AIDS, seed=42, device=dev)
+        s_lo, s_hi = a.sessions * rank // world, a.sessions * (rank + 1) // world
+        e_lo, e_hi = int(full['sess_off'][s_lo]), int(full['sess_off'][s_hi])
+        data = {'aid': full['aid'][e_lo:e_hi].contiguous(), 'ts': full['ts'][e_lo:e_hi].contiguous(),
+                'type': full['type'][e_lo:e_hi].contiguous(), 'sess_off': (full['sess_off'][s_lo:s_hi + 1] - e_lo).contiguous(),
+                'n_aids': full['n_aids']}
+        del full
+        torch.cuda.empty_cache()
+    else:
+        data = generate_sessions_torch(a.sessions, n_aids=OTTO_N_AIDS, seed=42 + rank, device=dev)
     n_aids = data['n_aids']
     if world > 1:
         ts_min, ts_max = global_ts_range(data['ts'].cpu() if stage else data['ts'])
@@ -275,13 +333,15 @@ def main():
         cand = {n: kernel_ms.get(n, 0.0) for n in ('expand', 'index', 'partition', 'reduce_s', 'reduce_m', 'reduce_l')}
         dom = max(cand, key=cand.get)
         full_otto = world == 1 and a.sessions == 14_571_582 and a.k == 20
-        ksub = {'expand': ('k_expand',), 'index': ('k_bkt_',), 'partition': ('k_partition',),
-                'reduce_s': ('k_reduce<9,',), 'reduce_m': ('k_reduce<12,',), 'reduce_l': ('k_reduce<13,', 'k_reduce<14,')}
-        knames = {'expand': 'k_expand_fused<false> (windows of 8 / 16 / 32 lanes, general and gap-free, one launch)',
-                  'reduce_s': 'k_reduce<9, 64, 0, true, 5, 8>', 'reduce_m': 'k_reduce<12, 256, 0, true, 4, 8>',
-                  'reduce_l': 'k_reduce<14, 1024, 0, true, 4, 2> + k_reduce<13, 512, 0, true, 4, 4> (packed heavy aids) + k_reduce<13, 1024, 0, false, 4, 2> (wide)',
-                  'partition': 'k_partition<false> + k_partition<true>',
-                  'index': 'k_bkt_split<false/true> + k_bkt_local<false/true> + scans'}
+        # kernel names as the library reports them for the launches of the last step (what rocprofv3 lists)
+        knames = eng.kernel_names()
+        if world > 1:
+            knames['expand'] = builder.local.kernel_names()['expand']
+        # the traffic file is keyed by rocprofv3's kernel names: exact instantiations where a slot is one template, prefixes
+        # for the index / partition slots (several small kernels)
+        ksub = {slot: tuple(n for n in names.split(' + ') if '<' in n and '/' not in n and '*' not in n) for slot, names in knames.items()}
+        ksub['index'] = ('k_bkt_split', 'k_bkt_local')
+        ksub['partition'] = ('k_partition',)
         result = {
             'metric': 'aid-pairs/sec covisitation build',
             'value': round(pairs * a.steps / dt, 1),
@@ -289,15 +349,15 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(1e3 * dt / a.steps, 3),
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': a.scaling if world > 1 else 'weak',
             'vs_baseline': None,
             'dtype': 'u64',
             'data': 'synthetic',
             'config': {
-                'workload': f'full-OTTO-shape covisitation: {a.sessions} synthetic sessions per GPU, '
+                'workload': f'full-OTTO-shape covisitation: {a.sessions} synthetic sessions {"per GPU" if (world == 1 or a.scaling == "weak") else "in all, split by session chunk over the GPUs"}, '
                             f'{data["aid"].numel()} events, {n_aids} aids, window=30, max_gap=86400 s, '
                             f'3 type-weighted matrices (click/cart/order_weighted), top-{a.k}/aid',
-                'sessions_per_gpu': a.sessions, 'events_per_gpu': int(data['aid'].numel()),
+                'sessions_per_gpu': int(data['sess_off'].numel() - 1), 'events_per_gpu': int(data['aid'].numel()),
                 'pairs_total': int(pairs), 'kinds': list(BENCH_KINDS), 'k': a.k,
                 'parallelism': 'single GPU' if world == 1 else f'session-chunk x{world}, RCCL all-to-all-v of expanded runs by aid_x owner',
             },
@@ -306,12 +366,15 @@ def main():
             'kernel_ms': {k_: round(v, 3) for k_, v in kernel_ms.items()},
             'stats': st,
         }
+    # ---- the real drop-in workload (covisitation/builder.py:build_matrices): all 7 reference kinds, k = 20, N = 1 ------
+    if rank == 0 and world == 1 and not a.no_dropin:
+        try:
+            result['dropin_7kinds'] = dropin_leg(data, dev, n_aids, ts_min, ts_max, a.k)
+        except Exception as e:                                   # a reported extra, never a reason to lose the bench line
+            result['dropin_7kinds'] = {'error': repr(e)}
     # ---- second half of the metric: BPR-MF triplets/s ----------------------------------------------
     if not a.no_mf:
-        try:
-            from otto_amd.matrix_factorization import bench_mf
-        except ImportError:
-            bench_mf = None
+        import bench_mf
         if bench_mf is not None:
             del builder, eng, out
             torch.cuda.empty_cache()

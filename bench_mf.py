@@ -1,9 +1,10 @@
-"""MF half of bench.py's metric: BPR triplets/s (hogwild SGD, the north star's mode) on the
-OTTO-shape (session, aid) stream, plus the reference-config R-MF (SparseAdam) samples/s.
+"""MF half of bench.py's metric (benchmark harness, not product code): BPR triplets/s (hogwild SGD, the north star's
+mode) on the OTTO-shape (session, aid) stream, plus the reference-config R-MF (SparseAdam) samples/s and the full-sort
+scoring rate.
 
-Weak scaling for N > 1: every rank owns ``--mf-rows`` rows of its own session chunk (user rows are
-rank-private), the item table is replicated and its deltas are all-reduced over RCCL every
-``SYNC_EVERY`` launches (``bpr.sync_item_table``)."""
+N > 1: every rank owns the rows of its own session chunk (user rows are rank-private), the item table is replicated and
+the rows it touched are exchanged every ``SYNC_EVERY`` launches (``bpr.ItemTableSync``: sparse (row id, delta row)
+all-gather over RCCL). ``--scaling weak``: ``--mf-rows`` rows per rank; ``strong``: ``--mf-rows`` rows split over the ranks."""
 import time
 
 import numpy as np
@@ -16,14 +17,14 @@ HBM_PEAK_GBS = 8000.0
 def run(a, dev, rank, world, cpu_baseline_fn=None, traffic_fn=None):
     import torch
     import torch.distributed as dist
-    from ..synth import generate_sessions_torch, OTTO_N_AIDS, OTTO_N_SESSIONS
-    from .engine import MFEngine, BPR_HOGWILD
-    from .bpr import sync_item_table
+    from otto_amd.synth import generate_sessions_torch, OTTO_N_AIDS, OTTO_N_SESSIONS
+    from otto_amd.matrix_factorization.engine import MFEngine, BPR_HOGWILD
+    from otto_amd.matrix_factorization.bpr import ItemTableSync
     d = a.mf_factors
     n_users, n_items = (OTTO_N_SESSIONS if a.sessions >= OTTO_N_SESSIONS else a.sessions), OTTO_N_AIDS
     data = generate_sessions_torch(n_users, n_aids=n_items, seed=142 + rank, device=dev)
     E = data['aid'].numel()
-    rows = min(a.mf_rows, E)
+    rows = min(a.mf_rows if a.scaling == 'weak' else a.mf_rows // world, E)
     lens = data['sess_off'][1:] - data['sess_off'][:-1]
     users = torch.repeat_interleave(torch.arange(n_users, device=dev), lens, output_size=E)
     perm = torch.randperm(E, device=dev)[:rows]            # SGD visits rows in random order
@@ -34,7 +35,7 @@ def run(a, dev, rank, world, cpu_baseline_fn=None, traffic_fn=None):
     g.manual_seed(7)
     U = (torch.randn(n_users, d, device=dev, generator=g) * 0.1).contiguous()
     V = (torch.randn(n_items, d, device=dev, generator=g) * 0.1).contiguous()
-    V_snap = V.clone() if world > 1 else None
+    sync = ItemTableSync(V) if world > 1 else None
     eng = MFEngine(n_users, n_items, d, ROWS_PER_LAUNCH, device=dev)
     n_launch = (rows + ROWS_PER_LAUNCH - 1) // ROWS_PER_LAUNCH
     loss = torch.zeros(n_launch, device=dev)
@@ -49,8 +50,10 @@ def run(a, dev, rank, world, cpu_baseline_fn=None, traffic_fn=None):
             eng.bpr_step(U, V, users[lo:hi], items[lo:hi], 42, e, lo, 0.05, 0.0, BPR_HOGWILD, loss_sum=loss[q:q + 1])
             if timed:
                 ev1[q].record()
-            if world > 1 and ((q + 1) % SYNC_EVERY == 0 or q == n_launch - 1):
-                sync_item_table(V, V_snap)
+            if world > 1:
+                sync.touched(items[lo:hi])
+                if (q + 1) % SYNC_EVERY == 0 or q == n_launch - 1:
+                    sync.exchange()
 
     def barrier():
         if world > 1:
@@ -85,7 +88,7 @@ def run(a, dev, rank, world, cpu_baseline_fn=None, traffic_fn=None):
         'config': {'workload': f'BPR-MF hogwild SGD, {n_users} sessions x {n_items} aids x {d}-d fp32, {rows} (session, aid) rows per GPU '
                                f'in random order, uniform negatives from the counter RNG, launches of {ROWS_PER_LAUNCH}',
                    'rows_per_gpu': rows, 'factors': d,
-                   'parallelism': 'single GPU' if world == 1 else f'data-parallel x{world}: user rows private, item-table deltas all-reduced (RCCL) every {SYNC_EVERY} launches'},
+                   'parallelism': 'single GPU' if world == 1 else f'data-parallel x{world} ({a.scaling} scaling): user rows private, touched item rows exchanged as sparse (id, delta row) all-gather (RCCL) every {SYNC_EVERY} launches'},
         'roofline': {'kernel': 'k_bpr_hogwild', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(gbs / HBM_PEAK_GBS, 4),
                      'traffic': traffic_fn(('k_bpr_hogwild',)) if (traffic_fn and d == 64 and rows >= ROWS_PER_LAUNCH) else None,
@@ -112,11 +115,21 @@ def run(a, dev, rank, world, cpu_baseline_fn=None, traffic_fn=None):
             er.step_sparse_adam(E1, st[0], st[1], E2, st[2], st[3], users[sl], items[sl], tg[sl], 0, 0.05, (0.9, 0.999), 1e-8, b + 3, lo_)
         torch.cuda.synchronize()
         dtr = time.perf_counter() - t1
-        res['rmf_sparse_adam'] = {'value': round(nb * B / dtr, 1), 'unit': 'samples/s', 'ms_per_batch': round(1e3 * dtr / nb, 3),
-                                  'config': f'MatrixFactorization MSELoss SparseAdam, {dr} factors, batch {B} (reference config.yaml)'}
+        # algorithmic bytes of one step (SURVEY.md section 8 d): 24 B of indices/target + 2 gathered rows per sample, and
+        # per UNIQUE touched row p, m, v read and written once (6 x 4d)
+        uniq = sum(int(torch.unique(c[b * B:(b + 1) * B]).numel()) for c in (users, items) for b in range(min(nb, 4))) / min(nb, 4)
+        rmf_bytes = B * (24 + 2 * 4 * dr) + uniq * 6 * 4 * dr
+        rmf_ms = 1e3 * dtr / nb
+        res['rmf_sparse_adam'] = {'value': round(nb * B / dtr, 1), 'unit': 'samples/s', 'ms_per_batch': round(rmf_ms, 3),
+                                  'config': f'MatrixFactorization MSELoss SparseAdam, {dr} factors, batch {B} (reference config.yaml)',
+                                  'roofline': {'kernel': 'k_rmf_fwd + k_rmf_acc + k_rmf_apply (one optimizer step)', 'bound': 'hbm',
+                                               'achieved': round(rmf_bytes / (rmf_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                               'frac': round(rmf_bytes / (rmf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None,
+                                               'avg_ms': round(rmf_ms, 4), 'algorithmic_bytes': int(rmf_bytes),
+                                               'unique_rows_per_batch': int(uniq)}}
         del E1, E2, st, er
         # full-sort scoring (recbole/inference.py:334: test batches of 4096 sessions x all items), d = 128 (config 5)
-        from .engine import score_topk
+        from otto_amd.matrix_factorization.engine import score_topk
         Bs, ds = 4096, 128
         Us = torch.randn(Bs, ds, device=dev, generator=g)
         Vs = torch.randn(n_items + 1, ds, device=dev, generator=g)      # + PAD row 0

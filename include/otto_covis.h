@@ -171,6 +171,9 @@ enum {
     OTTO_COVIS_T_COUNT
 };
 int otto_covis_timings(otto_covis_ctx* ctx, float* out_ms /* [OTTO_COVIS_T_COUNT] */);
+/* Names of the kernels (template instantiations) launched under timing slot `slot` since the last reset, joined by " + "
+ * (what a rocprofv3 kernel trace of the same run lists): bench.py labels its roofline objects with these. */
+int otto_covis_kernel_names(otto_covis_ctx* ctx, int32_t slot, char* buf, int32_t n);
 
 /* PMC calibration helper: streams n_u32 * 4 bytes with one 4-byte access per lane (write != 0: stores, else loads),
  * the access shape of the covisitation kernels, so FETCH_SIZE / WRITE_SIZE can be scaled to bytes (tools/pmc_traffic.py). */

@@ -85,6 +85,10 @@ int otto_mf_bpr_step(otto_mf_ctx* ctx, float* d_U, float* d_V, const int64_t* d_
 int otto_mf_score_topk(const float* d_U, const float* d_V, int64_t B, int64_t N, int32_t d, int32_t k,
                        int64_t pad_col, int32_t* d_ids, float* d_scores, void* d_workspace, int64_t workspace_bytes,
                        void* stream);
+/* Exact merge of n_lists partial top-k lists per row (item-sharded scoring across GPUs, SURVEY.md section 8 e): d_part_scores /
+ * d_part_ids are [n_lists][B][k] (id -1 or 0x7FFFFFFF = empty slot); output as otto_mf_score_topk, (score desc, id asc). */
+int otto_mf_topk_merge(const float* d_part_scores, const int32_t* d_part_ids, int32_t n_lists, int64_t B, int32_t k,
+                       int32_t* d_ids, float* d_scores, void* stream);
 /* bytes of workspace otto_mf_score_topk needs for (B, k) */
 int64_t otto_mf_score_workspace(int64_t B, int64_t N, int32_t k);
 

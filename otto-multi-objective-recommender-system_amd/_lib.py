@@ -86,6 +86,7 @@ SIGNATURES = {
     'otto_covis_export_fill': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     'otto_covis_copy_records': (_i32, [_vp, _vp, _vp, _vp, _vp]),
     'otto_covis_timings': (_i32, [_vp, C.POINTER(C.c_float)]),
+    'otto_covis_kernel_names': (_i32, [_vp, _i32, C.c_char_p, _i32]),
     'otto_debug_calibrate': (_i32, [_vp, _i64, _i32, _vp]),
     # include/otto_cand.h
     'otto_cand_lookup': (_i32, [C.POINTER(CandParams), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
@@ -104,6 +105,7 @@ SIGNATURES = {
                                 _i32, _vp, _vp, _vp]),
     'otto_mf_score_topk': (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _i64, _vp]),
     'otto_mf_score_workspace': (_i64, [_i64, _i64, _i32]),
+    'otto_mf_topk_merge': (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -120,6 +120,15 @@ class CovisBuilder:
         self._lib.otto_covis_timings(self._ctx, buf)
         return dict(zip(_lib.TIMING_NAMES, [float(v) for v in buf]))
 
+    def kernel_names(self):
+        """{timing slot: kernels launched under it since the last reset} as the library itself reports them."""
+        out = {}
+        for i, name in enumerate(_lib.TIMING_NAMES):
+            buf = C.create_string_buffer(1024)
+            _lib.check(self._lib.otto_covis_kernel_names(self._ctx, i, buf, 1024), 'otto_covis_kernel_names')
+            out[name] = buf.value.decode()
+        return out
+
     def copy_records(self):
         """Test hook: raw K1 output on the host (rec, tw or None, run_x, run_desc)."""
         st = self.stats()

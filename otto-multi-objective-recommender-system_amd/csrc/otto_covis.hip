@@ -2514,11 +2514,24 @@ struct otto_covis_ctx {
     int exp_planned = 0;
     int64_t retries = 0;
     uint32_t l_cap = L_CAP;
+    std::string knames[OTTO_COVIS_T_COUNT];   // kernels launched under each timing slot since the last reset (otto_covis_kernel_names)
     hipEvent_t ev[2 * OTTO_COVIS_T_COUNT];
     bool ev_set[OTTO_COVIS_T_COUNT];
     bool ev_ok = false;
 };
 
+// remember the kernel (template instantiation) launched under timing slot i, once per distinct name
+static void kname(otto_covis_ctx* c, int i, const char* fmt, ...) {
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    std::string& d = c->knames[i];
+    if (d.find(buf) != std::string::npos) return;
+    if (!d.empty()) d += " + ";
+    d += buf;
+}
 static void tbegin(otto_covis_ctx* c, int i, hipStream_t s) {
     if (c->ev_ok) { (void)hipEventRecord(c->ev[2 * i], s); }
 }
@@ -2573,6 +2586,7 @@ extern "C" int otto_covis_reset(otto_covis_ctx* c) {
     c->n_pairs = c->n_runs = 0;
     c->n_items[0] = c->n_items[1] = c->n_items[2] = 0;
     memset(c->ev_set, 0, sizeof c->ev_set);
+    for (auto& n : c->knames) n.clear();
     return 0;
 }
 
@@ -2626,6 +2640,7 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
         else OTTO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_expand_fused<false>, 256, 0));
         const int64_t resident = (int64_t)(per_cu > 0 ? per_cu : 4) * (n_cu > 0 ? n_cu : 256);   // one round of resident workgroups
         const int grid = (int)(blocks < resident ? blocks : resident);
+        kname(c, OTTO_COVIS_T_EXPAND, "k_expand_fused<%s>", p.want_time ? "true" : "false");
         if (p.want_time) k_expand_fused<true><<<grid, 256, 0, s>>>(a, n_sess, c->fast_path);
         else k_expand_fused<false><<<grid, 256, 0, s>>>(a, n_sess, c->fast_path);
         OTTO_HIP(hipGetLastError());
@@ -2693,6 +2708,7 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
         const int grid = (int)(blocks < 256 * 16 ? blocks : 256 * 16);
         const int variant = (p.want_time ? 2 : 0) | (p.n_filters > 0 ? 1 : 0);
 #define OTTO_EXPAND(G)                                                                   \
+        kname(c, OTTO_COVIS_T_EXPAND, fast ? "k_expand_fast<%d, %s>" : "k_expand<%d, %s, %s>", G, p.want_time ? "true" : "false", p.n_filters > 0 ? "true" : "false"); \
         if (fast) {                                                                      \
             if (p.want_time) k_expand_fast<G, true><<<grid, 256, 0, s>>>(a);             \
             else k_expand_fast<G, false><<<grid, 256, 0, s>>>(a);                        \
@@ -2804,6 +2820,7 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
         ba.bcount = c->bcount.as<uint32_t>();
         const int64_t n_chunks = (n_slots + BKT_CHUNK - 1) / BKT_CHUNK;
         const int sgrid = (int)(n_chunks < 256 * 2 ? n_chunks : 256 * 2);
+        kname(c, OTTO_COVIS_T_INDEX, "k_bkt_split<false/true> + k_bkt_local<false/true> + k_scan_* + k_fill_*");
         k_bkt_split<false><<<sgrid, BKT_THREADS, 0, s>>>(ba);
         OTTO_HIP(hipGetLastError());
         OTTO_TRY(device_scan(BktCount{ba.bcount}, (int64_t)ba.nb, c->bstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
@@ -2822,6 +2839,7 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
         OTTO_HIP(hipGetLastError());
     } else if (n_slots) {
         int grid = (int)((n_slots + 255) / 256 < 256 * 32 ? (n_slots + 255) / 256 : 256 * 32);
+        kname(c, OTTO_COVIS_T_INDEX, "k_hist_runs + k_scatter_runs + k_scan_* + k_fill_*");
         k_hist_runs<<<grid, 256, 0, s>>>(c->run_x.as<uint32_t>(), c->run_desc.as<uint64_t>(), n_slots, c->cnt64.as<uint64_t>(),
                                          c->run_rank.as<uint32_t>(), n_aids);
         OTTO_HIP(hipGetLastError());
@@ -2863,9 +2881,13 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
     return 0;
 }
 
+static void reduce_name(otto_covis_ctx* c, int slot, int log2t, int threads, int group, bool packed, int minw, int gu) {
+    kname(c, slot, "k_reduce<%d, %d, %d, %s, %d, %d, 1, false>", log2t, threads, group, packed ? "true" : "false", minw, gu);
+}
 // the diagnostics instantiation (DBG) exists for the TYPE group only (the bench path); debug_skip is ignored elsewhere
-#define OTTO_LAUNCH_REDUCE(grid, threads, args, ...)                                                   \
+#define OTTO_LAUNCH_REDUCE(slot, grid, threads, args, ...)                                             \
     do {                                                                                               \
+        reduce_name(c, slot, __VA_ARGS__);                                                             \
         if (GROUP == OTTO_COVIS_GROUP_TYPE && (args).debug_skip)                                       \
             k_reduce<__VA_ARGS__, 1, GROUP == OTTO_COVIS_GROUP_TYPE><<<grid, threads, 0, s>>>(args);   \
         else                                                                                           \
@@ -2907,14 +2929,14 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
         uint32_t grid = a.n_items < 256u * 20u ? a.n_items : 256u * 20u;
         tbegin(c, OTTO_COVIS_T_REDUCE_S, s);
         prof_begin();
-        OTTO_LAUNCH_REDUCE(grid, S_THREADS, a, S_LOG2T, S_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, 5, 8);
+        OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_S, grid, S_THREADS, a, S_LOG2T, S_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, 5, 8);
         prof_end("S", a.n_work);
         tend(c, OTTO_COVIS_T_REDUCE_S, s);
     } else if (bin == 1) {
         uint32_t grid = a.n_items < 256u * 4u ? a.n_items : 256u * 4u;
         tbegin(c, OTTO_COVIS_T_REDUCE_M, s);
         prof_begin();
-        OTTO_LAUNCH_REDUCE(grid, M_THREADS, a, M_LOG2T, M_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, (GROUP != OTTO_COVIS_GROUP_TIME ? 4 : 2), 8);
+        OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_M, grid, M_THREADS, a, M_LOG2T, M_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, (GROUP != OTTO_COVIS_GROUP_TIME ? 4 : 2), 8);
         prof_end("M", a.n_work);
         tend(c, OTTO_COVIS_T_REDUCE_M, s);
     } else {
@@ -2938,6 +2960,7 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
                         a.allow_packed};
             const uint32_t pgrid = (uint32_t)(c->n_chunks < 256u * 5u ? c->n_chunks : 256u * 5u);
             const uint32_t cgrid = (uint32_t)(c->n_chunks < 256u * 8u ? c->n_chunks : 256u * 8u);
+            kname(c, OTTO_COVIS_T_PARTITION, "k_partition<false> + k_partition<true>");
             k_partition<false><<<cgrid, 256, 0, s>>>(pa);
             OTTO_HIP(hipGetLastError());
             OTTO_TRY(device_scan(PCount{c->pcount.as<uint32_t>()}, (int64_t)a.n_items, c->pstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
@@ -2960,16 +2983,16 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
             if (mode == 2) {
                 if constexpr (GROUP != OTTO_COVIS_GROUP_TIME) {
                     const uint32_t grid = am.n_work < 256u * 2u ? am.n_work : 256u * 2u;
-                    OTTO_LAUNCH_REDUCE(grid, 512, am, L_LOG2T, 512, GROUP, true, 4, 4);
+                    OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_L, grid, 512, am, L_LOG2T, 512, GROUP, true, 4, 4);
                 }
             } else if (mode == 1) {
                 if constexpr (GROUP != OTTO_COVIS_GROUP_TIME) {
                     const uint32_t grid = am.n_work < 256u ? am.n_work : 256u;
-                    OTTO_LAUNCH_REDUCE(grid, L_THREADS, am, LP_LOG2T, L_THREADS, GROUP, true, 4, 2);
+                    OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_L, grid, L_THREADS, am, LP_LOG2T, L_THREADS, GROUP, true, 4, 2);
                 }
             } else {
                 const uint32_t grid = am.n_work < 256u ? am.n_work : 256u;
-                OTTO_LAUNCH_REDUCE(grid, L_THREADS, am, L_LOG2T, L_THREADS, GROUP, false, 4, 2);
+                OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_L, grid, L_THREADS, am, L_LOG2T, L_THREADS, GROUP, false, 4, 2);
             }
             prof_end(mode == 2 ? "L packed 2^13 x512" : (mode == 1 ? "L packed 2^14 x1024" : "L wide 2^13 x1024"), am.n_work);
             OTTO_HIP(hipGetLastError());
@@ -2977,6 +3000,7 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
         tend(c, OTTO_COVIS_T_REDUCE_L, s);
         OTTO_HIP(hipGetLastError());
         tbegin(c, OTTO_COVIS_T_MERGE, s);
+        kname(c, OTTO_COVIS_T_MERGE, "k_merge<%d>", GROUP);
         k_merge<GROUP><<<a.n_items, 64, 0, s>>>(a);
         tend(c, OTTO_COVIS_T_MERGE, s);
     }
@@ -3156,6 +3180,13 @@ extern "C" int otto_covis_timings(otto_covis_ctx* c, float* out_ms) {
         }
     }
     return OTTO_COVIS_T_COUNT;
+}
+
+extern "C" int otto_covis_kernel_names(otto_covis_ctx* c, int32_t slot, char* buf, int32_t n) {
+    OTTO_REQUIRE(c && buf && n > 0, "null argument");
+    OTTO_REQUIRE(slot >= 0 && slot < OTTO_COVIS_T_COUNT, "timing slot %d out of range", slot);
+    snprintf(buf, (size_t)n, "%s", c->knames[slot].c_str());
+    return 0;
 }
 
 extern "C" int otto_covis_copy_records(otto_covis_ctx* c, uint32_t* h_rec, uint32_t* h_tw, uint32_t* h_run_x,

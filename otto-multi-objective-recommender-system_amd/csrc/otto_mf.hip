@@ -620,6 +620,7 @@ __global__ __launch_bounds__(64) void k_score_merge(const float* part_s, const i
             const int64_t o = ((int64_t)(c / k) * Bpad + row) * k + (c % k);
             cs = part_s[o];
             ci = part_i[o];
+            if (ci < 0) ci = 0x7FFFFFFF;          // -1: an empty slot of a gathered partial list
         }
         auto better = [](float s1, int32_t i1, float s2, int32_t i2) { return s1 > s2 || (s1 == s2 && i1 < i2); };
         float ts = __shfl(bs, k - 1, 64);
@@ -889,6 +890,15 @@ extern "C" int otto_mf_score_topk(const float* U, const float* V, int64_t B, int
     }
     OTTO_HIP(hipGetLastError());
     k_score_merge<<<(unsigned)B, 64, 0, s>>>(a.part_s, a.part_i, ns, Bpad, B, k, ids, scores);
+    OTTO_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int otto_mf_topk_merge(const float* part_scores, const int32_t* part_ids, int32_t n_lists, int64_t B, int32_t k,
+                                  int32_t* ids, float* scores, void* stream) {
+    OTTO_REQUIRE(part_scores && part_ids && ids && scores, "null argument");
+    OTTO_REQUIRE(n_lists >= 1 && B > 0 && k >= 1 && k <= SC_MAXK, "bad n_lists / B / k");
+    k_score_merge<<<(unsigned)B, 64, 0, (hipStream_t)stream>>>(part_scores, part_ids, n_lists, B, B, k, ids, scores);
     OTTO_HIP(hipGetLastError());
     return 0;
 }

@@ -150,3 +150,23 @@ def score_topk(U, V, k=20, pad_col=-1):
                                           _ptr(ws), ws_bytes, C.c_void_p(torch.cuda.current_stream(U.device).cuda_stream)),
                    'otto_mf_score_topk')
     return ids, scores
+
+
+def topk_merge(part_scores, part_ids, k):
+    """Exact merge of W partial top-k lists per row: ``part_scores`` float32 / ``part_ids`` int32 [W, B, k] (id -1 = empty)
+    -> (ids int32 [B, k], scores float32 [B, k]) ordered by (score desc, id asc). Used by the item-sharded scoring."""
+    import torch
+    if part_scores.device.type != 'cuda':
+        raise _lib.OttoError('topk_merge needs a ROCm device (no CPU fallback)')
+    _chk('part_scores', part_scores, torch.float32, part_scores.device)
+    _chk('part_ids', part_ids, torch.int32, part_scores.device)
+    W, B, kk = part_scores.shape
+    if part_ids.shape != part_scores.shape or kk != k:
+        raise ValueError('partial lists must be [W, B, k]')
+    ids = torch.empty((B, k), dtype=torch.int32, device=part_scores.device)
+    scores = torch.empty((B, k), dtype=torch.float32, device=part_scores.device)
+    with torch.cuda.device(part_scores.device):
+        _lib.check(_lib.lib().otto_mf_topk_merge(_ptr(part_scores), _ptr(part_ids), int(W), int(B), int(k), _ptr(ids), _ptr(scores),
+                                                 C.c_void_p(torch.cuda.current_stream(part_scores.device).cuda_stream)),
+                   'otto_mf_topk_merge')
+    return ids, scores

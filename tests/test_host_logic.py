@@ -172,6 +172,64 @@ def test_item_table_delta_allreduce_world2():
         assert np.array_equal(res[r][0], want) and np.array_equal(res[r][1], want)
 
 
+def _table_sync_worker(rank, world, port, q):
+    """ItemTableSync under gloo: three periods of rank-local updates (a dense, asynchronous exchange, then a sparse one,
+    then the drain), replicas must end bit-identical and equal to init + the sum of every rank's updates."""
+    import sys
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from otto_amd.matrix_factorization.bpr import ItemTableSync
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(5)
+    n, d = 4000, 8
+    V = torch.randn(n, d, generator=g)
+    sync = ItemTableSync(V, sparse_fraction=0.125)
+    total = torch.zeros_like(V)
+    gr = torch.Generator().manual_seed(100 + rank)
+    every = [torch.Generator().manual_seed(100 + r) for r in range(world)]
+
+    def period(gen, rows):
+        ids = torch.randint(0, n, (rows,), generator=gen)
+        upd = torch.randn(rows, d, generator=gen)
+        return ids, upd
+    for rows, mark in ((3000, False), (40, True), (25, True)):          # period 1 dense (no marks), 2 and 3 sparse
+        ids, upd = period(gr, rows)
+        V.index_add_(0, ids, upd)
+        if mark:
+            sync.touched(ids)
+        for gen in every:                                               # what the sum of all ranks' updates must be
+            i2, u2 = period(gen, rows)
+            total.index_add_(0, i2, u2)
+        sync.exchange()
+    sync.finish()
+    q.put((rank, V.clone().numpy(), sync.base.clone().numpy(), total.numpy(), dict(sync.stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_item_table_sync_dense_async_and_sparse_world2():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_table_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict((r, rest) for r, *rest in (q.get(timeout=180) for _ in ps))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(5)
+    init = torch.randn(4000, 8, generator=g).numpy()
+    assert np.array_equal(res[0][0], res[1][0]), 'replicas differ after finish()'
+    assert np.array_equal(res[0][0], res[0][1])
+    assert res[0][3]['sparse'] == 2 and res[0][3]['dense'] >= 2          # period 1 + the drain
+    np.testing.assert_allclose(res[0][0], init + res[0][2], rtol=1e-5, atol=1e-5)
+
+
 def test_recency_oracle_hand_example():
     """oracle/recency_oracle.py on a hand-computed session: aids (5, 7, 5), types (click, cart, click).
     click curve 2^linspace(0.1, 1, 3) - 1 = (2^0.1 - 1, 2^0.55 - 1, 1); Counter: 5 -> w0 + w2, 7 -> 6 * w1."""

@@ -193,3 +193,122 @@ def test_streamed_host_ingest_equals_device_feed(gpu_device):
     for kind in kinds:
         for g, w in zip(topk_to_rows(*got[kind]), topk_to_rows(*want[kind])):
             assert np.array_equal(g, w), kind
+
+
+def _dp_worker(rank, world, port, q, root):
+    """One rank of the data-parallel MF test: both ranks share cuda:0 (the box has one GPU), gloo carries the collectives."""
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path[:0] = [root, os.path.join(root, 'oracle')]
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from otto_amd.matrix_factorization.bpr import BPR, ItemTableSync, train_epoch, full_sort_topk_sharded
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    u, i, held, n_users, n_items, d = _planted(128)
+    torch.manual_seed(0)
+    model = BPR(n_users, n_items, d)
+    with torch.no_grad():
+        model.user_embedding.weight.normal_(0, 0.1)
+        model.item_embedding.weight.normal_(0, 0.1)
+    model.to(dev)
+    # session-chunk shard: users [lo, hi) and their rows belong to this rank
+    lo, hi = n_users * rank // world, n_users * (rank + 1) // world
+    mine = (u >= lo) & (u < hi)
+    du, di = torch.from_numpy(u[mine]).to(dev), torch.from_numpy(i[mine]).to(dev)
+    row0 = int(np.flatnonzero(mine)[0])
+    sync = ItemTableSync(model.item_embedding.weight.data)
+    losses = [train_epoch(model, du, di, lr=0.2, seed=1, epoch=e, rows_per_launch=4096, row0=row0, sync=sync, sync_every=2)
+              for e in range(40)]
+    V = model.item_embedding.weight.data
+    # user rows are rank-private: gather them so every rank can score all users
+    U = model.user_embedding.weight.data
+    mask = torch.zeros(n_users, 1, device=dev)
+    mask[lo:hi] = 1
+    Uall = U * mask
+    dist.all_reduce(Uall)
+    ids_u, sc_u = full_sort_topk_sharded(Uall, V, k=20, pad_col=0, shard='users')
+    ids_i, sc_i = full_sort_topk_sharded(Uall, V, k=20, pad_col=0, shard='items')
+    from otto_amd.matrix_factorization.engine import score_topk
+    ids_1, sc_1 = score_topk(Uall, V, k=20, pad_col=0)
+    q.put((rank, V.cpu().numpy(), losses, ids_1.cpu().numpy(), sc_1.cpu().numpy(), ids_u.cpu().numpy(), sc_u.cpu().numpy(),
+           ids_i.cpu().numpy(), sc_i.cpu().numpy(), dict(sync.stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _planted(d, seed=0):
+    rng = np.random.default_rng(seed)
+    n_users, n_items, groups = 3000, 1501, 15
+    grp = rng.integers(0, groups, n_users)
+    item_grp = np.r_[-1, rng.integers(0, groups, n_items - 1)]     # item 0 = PAD
+    by = [np.flatnonzero(item_grp == g_) for g_ in range(groups)]
+    u = np.repeat(np.arange(n_users), 12)
+    i = np.array([rng.choice(by[grp[x]]) for x in u])
+    held = np.array([rng.choice(by[grp[x]]) for x in range(n_users)])
+    return u, i, held, n_users, n_items, d
+
+
+def test_data_parallel_bpr_two_ranks_and_sharded_scoring(gpu_device):
+    """BASELINE config 5 rehearsed with 2 processes on the one GPU (gloo carries the collectives): BPR d = 128,
+    sessions sharded by chunk, item table exchanged by ItemTableSync, then full-sort scoring sharded by users and by items.
+      * replicas of the item table are bit-identical after every epoch's drain;
+      * the loss curve and recall@20 stay within a band of the 1-rank run. The runs are not bit-equal: the ranks' deltas
+        are SUMMED (W ranks moving the same item row from the same base = up to W x the single-rank step on the item side,
+        so the 2-rank loss falls faster), and foreign deltas arrive one exchange period late (stale-synchronous). Band:
+        final loss not more than 15 % above the 1-rank loss, recall@20 not more than 0.05 below it;
+      * both sharded scorings return exactly the unsharded result."""
+    import queue
+    import socket
+    import torch.multiprocessing as mp
+    from conftest import ROOT
+    import mf_oracle as mo
+    from otto_amd.matrix_factorization.bpr import BPR, train_epoch
+    from otto_amd.matrix_factorization.engine import score_topk
+    u, i, held, n_users, n_items, d = _planted(128)
+    torch.manual_seed(0)
+    ref = BPR(n_users, n_items, d)
+    with torch.no_grad():
+        ref.user_embedding.weight.normal_(0, 0.1)
+        ref.item_embedding.weight.normal_(0, 0.1)
+    ref.to(gpu_device)
+    du, di = torch.from_numpy(u).to(gpu_device), torch.from_numpy(i).to(gpu_device)
+    ref_losses = [train_epoch(ref, du, di, lr=0.2, seed=1, epoch=e, rows_per_launch=8192) for e in range(40)]
+    ids_ref, _ = ref.full_sort_topk(torch.arange(n_users, device=gpu_device), k=20, pad_col=0)
+    r_ref = np.mean([mo.click_recall([h], row.tolist()) for h, row in zip(held, ids_ref.cpu().numpy())])
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, ROOT)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in range(300):
+        try:
+            r, *rest = q.get(timeout=1)
+            res[r] = rest
+            if len(res) == 2:
+                break
+        except queue.Empty:
+            if not all(p.is_alive() for p in ps) and q.empty():
+                break
+    for p in ps:
+        p.join(60)
+    assert len(res) == 2 and all(p.exitcode == 0 for p in ps), 'a data-parallel worker failed'
+    V0, l0, id1, sc1, idu, scu, idi, sci, stats = res[0]
+    V1 = res[1][0]
+    assert np.array_equal(V0, V1), 'item-table replicas differ after the drain'
+    assert stats['dense'] + stats['sparse'] > 0
+    mean_loss = (np.array(l0) + np.array(res[1][1])) / 2
+    assert mean_loss[-1] < 0.5 * mean_loss[0]
+    assert mean_loss[-1] <= 1.15 * ref_losses[-1], (mean_loss[-1], ref_losses[-1])
+    r_dp = np.mean([mo.click_recall([h], row.tolist()) for h, row in zip(held, id1)])
+    assert r_ref > 0.1 and r_dp >= r_ref - 0.05, (r_dp, r_ref)
+    for got_i, got_s in ((idu, scu), (idi, sci)):
+        assert np.array_equal(got_i, id1) and np.array_equal(got_s, sc1), 'sharded scoring differs from the unsharded call'
+    assert np.array_equal(res[1][6], idi) and np.array_equal(res[1][4], idu)      # every rank holds the full result

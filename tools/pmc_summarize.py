@@ -35,6 +35,10 @@ for k in sorted(set(fetch) | set(write)):
         continue
     out['kernels'][k[:90]] = {'launches': n, 'read_bytes_per_launch': int(rd), 'write_bytes_per_launch': int(wr),
                               'traffic_bytes_per_launch': int(rd + wr)}
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+out['source_hash'] = bench.source_hash()      # bench.py attaches these numbers only while the kernel sources are unchanged
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print(json.dumps(out['calibration']))
 for k, v in out['kernels'].items():
