@@ -91,6 +91,10 @@ SIGNATURES = {
     # include/otto_cand.h
     'otto_cand_lookup': (_i32, [C.POINTER(CandParams), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     'otto_recency_candidates': (_i32, [C.POINTER(RecencyParams), _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    # include/otto_events.h
+    'otto_events_sort_workspace': (_i64, [_i64]),
+    'otto_events_sort': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _p_i64, _vp, _i64, _vp]),
+    'otto_events_type_from_strings': (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     # include/otto_mf.h
     'otto_mf_create': (_i32, [C.POINTER(_vp), _i64, _i64, _i32, _i64, _i32]),
     'otto_mf_destroy': (None, [_vp]),

@@ -19,6 +19,7 @@
 //              when a sibling partition's threshold is known) + exact merge
 #include "common.h"
 #include "topk.h"
+#include "scan.h"
 #include "../../include/otto_covis.h"
 
 #include <stdarg.h>
@@ -37,78 +38,6 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
     g_err = buf;
 }
-
-// ---------------------------------------------------------------------------
-// generic 3-phase exclusive scan of f(i), i in [0, n): out[i] = sum_{j<i} f(j), out[n] = total
-// ---------------------------------------------------------------------------
-constexpr int SCAN_THREADS = 1024;
-constexpr int SCAN_ITEMS = 4;
-constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
-
-template <typename F>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_sum(F f, int64_t n, uint64_t* partial) {
-    __shared__ uint64_t sm[SCAN_THREADS / 64 + 1];
-    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
-    uint64_t v = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < n) v += f(base + k);
-    uint64_t tot;
-    (void)block_excl_scan<uint64_t, SCAN_THREADS>(v, sm, &tot);
-    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_partials(uint64_t* partial, int nb) {
-    __shared__ uint64_t sm[SCAN_THREADS / 64 + 1];
-    uint64_t run = 0;
-    for (int b0 = 0; b0 < nb; b0 += SCAN_THREADS) {
-        int i = b0 + threadIdx.x;
-        uint64_t v = i < nb ? partial[i] : 0;
-        uint64_t tot;
-        uint64_t ex = block_excl_scan<uint64_t, SCAN_THREADS>(v, sm, &tot);
-        if (i < nb) partial[i] = run + ex;
-        run += tot;
-    }
-    if (threadIdx.x == 0) partial[nb] = run;
-}
-
-template <typename F>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_write(F f, int64_t n, const uint64_t* partial, int nb,
-                                                              uint64_t* out) {
-    __shared__ uint64_t sm[SCAN_THREADS / 64 + 1];
-    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
-    uint64_t x[SCAN_ITEMS];
-    uint64_t v = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        x[k] = (base + k < n) ? f(base + k) : 0;
-        v += x[k];
-    }
-    uint64_t tot;
-    uint64_t ex = block_excl_scan<uint64_t, SCAN_THREADS>(v, sm, &tot) + partial[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (base + k < n) out[base + k] = ex;
-        ex += x[k];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = partial[nb];
-}
-
-// out must hold n+1 entries, partial ceil(n/TILE)+1 entries.
-template <typename F>
-static int device_scan(F f, int64_t n, uint64_t* out, uint64_t* partial, hipStream_t s) {
-    int nb = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
-    if (nb == 0) {
-        OTTO_HIP(hipMemsetAsync(out, 0, sizeof(uint64_t), s));
-        return 0;
-    }
-    k_scan_sum<F><<<nb, SCAN_THREADS, 0, s>>>(f, n, partial);
-    k_scan_partials<<<1, SCAN_THREADS, 0, s>>>(partial, nb);
-    k_scan_write<F><<<nb, SCAN_THREADS, 0, s>>>(f, n, partial, nb, out);
-    OTTO_HIP(hipGetLastError());
-    return 0;
-}
-static size_t scan_partial_bytes(int64_t n) { return ((size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 1) * sizeof(uint64_t); }
 
 // ---------------------------------------------------------------------------
 // winscan functors
@@ -1163,13 +1092,15 @@ struct PartArgs {
     int allow_packed;
 };
 
-template <bool SCATTER>
+// TW: the time channel travels with the records (GROUP_TIME): staged and scattered alongside
+template <bool SCATTER, bool TW>
 __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
     constexpr int NW = 4;
     constexpr int RL = 1 << (SCATTER ? PART_STAGE_LOG2R : PART_LDS_LOG2R);
     __shared__ uint32_t s_cnt[RL];                     // histogram, then staging cursors
     __shared__ uint32_t s_delta[SCATTER ? RL : 1];     // (global bucket position - position in the stage) per partition
     __shared__ uint32_t s_stage[SCATTER ? PART_STAGE : 1];
+    __shared__ uint32_t s_stage_tw[(SCATTER && TW) ? PART_STAGE : 1];
     __shared__ uint32_t s_scan[256 / 64 + 1];
     const int wid = threadIdx.x >> 6;
     for (uint32_t ci = blockIdx.x; ci < a.n_chunks; ci += gridDim.x) {
@@ -1185,7 +1116,7 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
         uint64_t re = rb + PART_CHUNK_RUNS;
         if (re > a.run_start[x + 1]) re = a.run_start[x + 1];
         const bool direct = lgR > (SCATTER ? PART_STAGE_LOG2R : PART_LDS_LOG2R) || (a.cnt64[x] & CNT_REC_MASK) >= (1ull << 32) ||
-                            (SCATTER && a.ptw != nullptr) || (SCATTER && a.window_max * PART_CHUNK_RUNS > PART_STAGE);
+                            (SCATTER && a.window_max * PART_CHUNK_RUNS > PART_STAGE);
         if (direct) {
             // no LDS staging (giant aids, or the time channel travels along): global cursor per record
             for_each_record<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t slot) {
@@ -1235,15 +1166,19 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
                 }
             }
             __syncthreads();
-            for_each_record<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t) {
+            for_each_record<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t slot) {
                 const uint32_t p = (rec_hash(rc) >> pshift) & pmask;
-                s_stage[atomicAdd(&s_cnt[p], 1u)] = rc;
+                const uint32_t pos = atomicAdd(&s_cnt[p], 1u);
+                s_stage[pos] = rc;
+                if (TW) s_stage_tw[(SCATTER && TW) ? pos : 0] = a.tw[slot];
             });
             __syncthreads();
             // the stage is grouped by partition: consecutive threads write consecutive bucket addresses
             for (uint32_t i = threadIdx.x; i < total; i += 256) {
                 const uint32_t rc = s_stage[i];
-                a.prec[x_base + (uint32_t)(s_delta[(rec_hash(rc) >> pshift) & pmask] + i)] = rc;
+                const uint64_t o = x_base + (uint32_t)(s_delta[(rec_hash(rc) >> pshift) & pmask] + i);
+                a.prec[o] = rc;
+                if (TW) a.ptw[o] = s_stage_tw[(SCATTER && TW) ? i : 0];
             }
         }
         __syncthreads();
@@ -2961,10 +2896,11 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
             const uint32_t pgrid = (uint32_t)(c->n_chunks < 256u * 5u ? c->n_chunks : 256u * 5u);
             const uint32_t cgrid = (uint32_t)(c->n_chunks < 256u * 8u ? c->n_chunks : 256u * 8u);
             kname(c, OTTO_COVIS_T_PARTITION, "k_partition<false> + k_partition<true>");
-            k_partition<false><<<cgrid, 256, 0, s>>>(pa);
+            k_partition<false, false><<<cgrid, 256, 0, s>>>(pa);
             OTTO_HIP(hipGetLastError());
             OTTO_TRY(device_scan(PCount{c->pcount.as<uint32_t>()}, (int64_t)a.n_items, c->pstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
-            k_partition<true><<<pgrid, 256, 0, s>>>(pa);
+            if (time) k_partition<true, true><<<pgrid, 256, 0, s>>>(pa);
+            else k_partition<true, false><<<pgrid, 256, 0, s>>>(pa);
             OTTO_HIP(hipGetLastError());
             tend(c, OTTO_COVIS_T_PARTITION, s);
             a.pstart = c->pstart.as<uint64_t>();

@@ -1,0 +1,273 @@
+// Device-side event ingest for MI355X (gfx950): stable (session, ts) sort of the event frame, CSR session offsets and
+// the event-type string map. C-ABI in include/otto_events.h. Reference code this replaces: the
+// pandas sort_values(['session', 'ts']) of src/ranker/aid_feature_engineering.py:40, the ms -> s division of :37 and the
+// type map of src/utilities/dataset_writer_pickle.py:29-33; host restatement otto_amd/events.py:frame_to_events.
+//
+// Sort: 8-bit LSD radix sort of (session << 32 | seconds, input index) pairs. One pass = block histograms of 4096-key
+// tiles -> exclusive scan over (digit, block) -> scatter with STABLE in-block ranks: a wave finds the lanes that hold
+// its digit with 8 ballots (no LDS traffic), a per-wave running count per digit (LDS, plain read-modify-write by the
+// first lane of each digit group) orders the wave's 16 chunks, and the waves of a block are ordered by a 256-thread
+// prefix over the per-wave counts. Digits that are constant over the whole input are skipped.
+#include "common.h"
+#include "scan.h"
+#include "../../include/otto_events.h"
+
+namespace otto {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;      // 4096 keys per block and pass
+constexpr int RS_WAVES = RS_THREADS / 64;
+
+struct SortWs {          // carved from the caller's workspace
+    uint64_t* key[2];
+    uint32_t* idx[2];
+    uint32_t* counts;    // [256 * nb]
+    uint64_t* offs;      // [256 * nb + 1]  (also: scan of the session-head flags, [n + 1])
+    uint64_t* partial;   // scan scratch
+    unsigned long long* orand;   // [2]: OR and AND of all keys; [2]: error counter of the type map
+};
+
+static int64_t rs_blocks(int64_t n) { return (n + RS_TILE - 1) / RS_TILE; }
+
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+static size_t ws_layout(int64_t n, char* base, SortWs* w) {
+    const int64_t nb = rs_blocks(n);
+    const size_t scan_n = (size_t)(256 * nb > n ? 256 * nb : n) + 1;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += align256(bytes); return p; };
+    char* k0 = take((size_t)n * 8); char* k1 = take((size_t)n * 8);
+    char* i0 = take((size_t)n * 4); char* i1 = take((size_t)n * 4);
+    char* c = take((size_t)256 * nb * 4);
+    char* f = take(scan_n * 8);
+    char* p = take(scan_partial_bytes((int64_t)scan_n));
+    char* oa = take(64);
+    if (w) {
+        w->key[0] = (uint64_t*)k0; w->key[1] = (uint64_t*)k1; w->idx[0] = (uint32_t*)i0; w->idx[1] = (uint32_t*)i1;
+        w->counts = (uint32_t*)c; w->offs = (uint64_t*)f; w->partial = (uint64_t*)p; w->orand = (unsigned long long*)oa;
+    }
+    return o;
+}
+
+__global__ __launch_bounds__(256) void k_make_keys(const uint32_t* session, const int64_t* ts, int64_t n, int64_t ts_div, uint64_t* key,
+                                                   uint32_t* idx, unsigned long long* orand, unsigned long long* bad) {
+    __shared__ unsigned long long s_or[4], s_and[4];
+    unsigned long long vo = 0, va = ~0ull;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t sec = ts[i] / ts_div;
+        if (sec < 0 || sec > 0x7FFFFFFFll) atomicAdd(bad, 1ull);
+        const uint64_t k = ((uint64_t)session[i] << 32) | (uint64_t)(uint32_t)sec;
+        key[i] = k;
+        idx[i] = (uint32_t)i;
+        vo |= k;
+        va &= k;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        vo |= __shfl_xor(vo, o, 64);
+        va &= __shfl_xor(va, o, 64);
+    }
+    if (lane_id() == 0) { s_or[threadIdx.x >> 6] = vo; s_and[threadIdx.x >> 6] = va; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicOr(&orand[0], s_or[0] | s_or[1] | s_or[2] | s_or[3]);
+        atomicAnd(&orand[1], s_and[0] & s_and[1] & s_and[2] & s_and[3]);
+    }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t* key, int64_t n, int shift, int64_t nb, uint32_t* counts) {
+    __shared__ uint32_t s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int c = 0; c < RS_ITEMS; ++c) {
+        const int64_t i = base + (int64_t)c * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&s_h[(key[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    counts[(int64_t)threadIdx.x * nb + blockIdx.x] = s_h[threadIdx.x];
+}
+
+struct CountAt {
+    const uint32_t* c;
+    __device__ uint64_t operator()(int64_t i) const { return c[i]; }
+};
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* key, const uint32_t* idx, int64_t n, int shift, int64_t nb,
+                                                           const uint64_t* offs, uint64_t* key_out, uint32_t* idx_out) {
+    __shared__ uint32_t s_wcnt[RS_WAVES][256];
+    __shared__ uint64_t s_wbase[RS_WAVES][256];
+    const int w = threadIdx.x >> 6;
+    const unsigned lane = lane_id();
+    for (int q = 0; q < RS_WAVES; ++q) s_wcnt[q][threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t wave_base = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * (RS_TILE / RS_WAVES);
+    uint64_t k[RS_ITEMS];
+    uint32_t id[RS_ITEMS], lr[RS_ITEMS];
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int c = 0; c < RS_ITEMS; ++c) {
+        const int64_t i = wave_base + (int64_t)c * 64 + lane;
+        const bool valid = i < n;
+        k[c] = valid ? key[i] : ~0ull;
+        id[c] = valid ? idx[i] : 0u;
+        const uint32_t dig = (uint32_t)(k[c] >> shift) & 255u;
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (dig >> b) & 1u;
+            const uint64_t bb = __ballot(bit);
+            m &= bit ? bb : ~bb;
+        }
+        const int leader = valid ? __ffsll((unsigned long long)m) - 1 : (int)lane;
+        uint32_t prev = 0;
+        if (valid && (int)lane == leader) {
+            prev = s_wcnt[w][dig];
+            s_wcnt[w][dig] = prev + (uint32_t)__popcll(m);
+        }
+        prev = (uint32_t)__shfl((int)prev, leader, 64);
+        lr[c] = prev + (uint32_t)__popcll(m & lt);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the next chunk's leaders read what this chunk's wrote
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {
+        uint64_t run = offs[(int64_t)threadIdx.x * nb + blockIdx.x];
+        for (int q = 0; q < RS_WAVES; ++q) {
+            s_wbase[q][threadIdx.x] = run;
+            run += s_wcnt[q][threadIdx.x];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < RS_ITEMS; ++c) {
+        const int64_t i = wave_base + (int64_t)c * 64 + lane;
+        if (i < n) {
+            const uint64_t d = s_wbase[w][(uint32_t)(k[c] >> shift) & 255u] + lr[c];
+            key_out[d] = k[c];
+            idx_out[d] = id[c];
+        }
+    }
+}
+
+struct HeadFlag {      // 1 where a new session starts in the sorted key stream
+    const uint64_t* key;
+    __device__ uint64_t operator()(int64_t i) const { return (i == 0 || (key[i] >> 32) != (key[i - 1] >> 32)) ? 1ull : 0ull; }
+};
+
+__global__ void k_emit_sorted(const uint64_t* key, const uint32_t* idx, int64_t n, const uint32_t* aid, const uint8_t* type,
+                              const uint64_t* head_pos, uint32_t* out_aid, int32_t* out_ts, uint8_t* out_type, uint32_t* out_order,
+                              int64_t* sess_off, uint32_t* sess_id) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = key[i];
+        const uint32_t src = idx[i];
+        out_aid[i] = aid[src];
+        out_type[i] = type[src];
+        out_ts[i] = (int32_t)(uint32_t)k;
+        if (out_order) out_order[i] = src;
+        if (i == 0 || (k >> 32) != (key[i - 1] >> 32)) {
+            const uint64_t p = head_pos[i];
+            sess_off[p] = i;
+            sess_id[p] = (uint32_t)(k >> 32);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) sess_off[head_pos[n]] = n;
+}
+
+template <typename OFF>
+__global__ void k_type_strings(const OFF* off, const uint8_t* bytes, int64_t n, uint8_t* out, unsigned long long* bad) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = (int64_t)off[i], len = (int64_t)off[i + 1] - o;
+        uint8_t t = 255;
+        if (len >= 2) {
+            const uint8_t c0 = bytes[o], c1 = bytes[o + 1];
+            if (c0 == 'c' && c1 == 'l' && len == 6) t = 0;          // clicks
+            else if (c0 == 'c' && c1 == 'a' && len == 5) t = 1;     // carts
+            else if (c0 == 'o' && c1 == 'r' && len == 6) t = 2;     // orders
+        }
+        if (t == 255) atomicAdd(bad, 1ull);
+        out[i] = t;
+    }
+}
+
+}  // namespace otto
+
+using namespace otto;
+
+extern "C" int64_t otto_events_sort_workspace(int64_t n) {
+    if (n <= 0) return 256;
+    return (int64_t)ws_layout(n, nullptr, nullptr);
+}
+
+extern "C" int otto_events_sort(const uint32_t* d_session, const int64_t* d_ts, const uint32_t* d_aid, const uint8_t* d_type, int64_t n,
+                                int64_t ts_div, uint32_t* d_out_aid, int32_t* d_out_ts, uint8_t* d_out_type, uint32_t* d_out_order,
+                                int64_t* d_sess_off, uint32_t* d_sess_id, int64_t* h_n_sessions, void* d_ws, int64_t ws_bytes,
+                                void* stream) {
+    OTTO_REQUIRE(h_n_sessions && d_sess_off, "otto_events_sort: null argument");
+    OTTO_REQUIRE(n >= 0 && n < (1ll << 32), "n must be in [0, 2^32)");
+    OTTO_REQUIRE(ts_div >= 1, "ts_div must be >= 1");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        *h_n_sessions = 0;
+        OTTO_HIP(hipMemsetAsync(d_sess_off, 0, 8, s));
+        return 0;
+    }
+    OTTO_REQUIRE(d_session && d_ts && d_aid && d_type && d_out_aid && d_out_ts && d_out_type && d_sess_id && d_ws, "otto_events_sort: null argument");
+    OTTO_REQUIRE(ws_bytes >= otto_events_sort_workspace(n), "workspace too small (%lld < %lld)", (long long)ws_bytes,
+                 (long long)otto_events_sort_workspace(n));
+    SortWs w;
+    ws_layout(n, (char*)d_ws, &w);
+    const int64_t nb = rs_blocks(n);
+    unsigned long long init[4] = {0ull, ~0ull, 0ull, 0ull};
+    OTTO_HIP(hipMemcpyAsync(w.orand, init, sizeof init, hipMemcpyHostToDevice, s));
+    const int grid = (int)((n + 255) / 256 < 256 * 16 ? (n + 255) / 256 : 256 * 16);
+    k_make_keys<<<grid, 256, 0, s>>>(d_session, d_ts, n, ts_div, w.key[0], w.idx[0], w.orand, w.orand + 2);
+    OTTO_HIP(hipGetLastError());
+    unsigned long long h[4];
+    OTTO_HIP(hipMemcpyAsync(h, w.orand, sizeof h, hipMemcpyDeviceToHost, s));
+    OTTO_HIP(hipStreamSynchronize(s));
+    OTTO_REQUIRE(h[2] == 0, "%llu timestamps are negative or beyond 2^31 - 1 seconds after dividing by %lld", h[2], (long long)ts_div);
+    const uint64_t varying = h[0] ^ h[1];                       // bits that differ somewhere in the input
+    int cur = 0;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 8 * pass;
+        if (((varying >> shift) & 255ull) == 0) continue;       // constant digit: the pass would be the identity
+        k_rs_hist<<<(unsigned)nb, RS_THREADS, 0, s>>>(w.key[cur], n, shift, nb, w.counts);
+        OTTO_HIP(hipGetLastError());
+        OTTO_TRY(device_scan(CountAt{w.counts}, 256 * nb, w.offs, w.partial, s));
+        k_rs_scatter<<<(unsigned)nb, RS_THREADS, 0, s>>>(w.key[cur], w.idx[cur], n, shift, nb, w.offs, w.key[cur ^ 1], w.idx[cur ^ 1]);
+        OTTO_HIP(hipGetLastError());
+        cur ^= 1;
+    }
+    OTTO_TRY(device_scan(HeadFlag{w.key[cur]}, n, w.offs, w.partial, s));
+    k_emit_sorted<<<grid, 256, 0, s>>>(w.key[cur], w.idx[cur], n, d_aid, d_type, w.offs, d_out_aid, d_out_ts, d_out_type, d_out_order,
+                                       d_sess_off, d_sess_id);
+    OTTO_HIP(hipGetLastError());
+    uint64_t ns = 0;
+    OTTO_HIP(hipMemcpyAsync(&ns, w.offs + n, 8, hipMemcpyDeviceToHost, s));
+    OTTO_HIP(hipStreamSynchronize(s));
+    *h_n_sessions = (int64_t)ns;
+    return 0;
+}
+
+extern "C" int otto_events_type_from_strings(const void* d_offsets, int32_t offsets_are_64, const uint8_t* d_bytes, int64_t n,
+                                             uint8_t* d_out_type, void* stream) {
+    OTTO_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return 0;
+    OTTO_REQUIRE(d_offsets && d_bytes && d_out_type, "otto_events_type_from_strings: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* bad = nullptr;
+    OTTO_HIP(hipMalloc(&bad, 8));
+    OTTO_HIP(hipMemsetAsync(bad, 0, 8, s));
+    const int grid = (int)((n + 255) / 256 < 256 * 16 ? (n + 255) / 256 : 256 * 16);
+    if (offsets_are_64) k_type_strings<int64_t><<<grid, 256, 0, s>>>((const int64_t*)d_offsets, d_bytes, n, d_out_type, bad);
+    else k_type_strings<int32_t><<<grid, 256, 0, s>>>((const int32_t*)d_offsets, d_bytes, n, d_out_type, bad);
+    unsigned long long hb = 0;
+    hipError_t e = hipMemcpyAsync(&hb, bad, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(bad);
+    OTTO_HIP(e);
+    OTTO_REQUIRE(hb == 0, "%llu event type strings are none of clicks / carts / orders", hb);
+    return 0;
+}

@@ -312,3 +312,48 @@ def test_data_parallel_bpr_two_ranks_and_sharded_scoring(gpu_device):
     for got_i, got_s in ((idu, scu), (idi, sci)):
         assert np.array_equal(got_i, id1) and np.array_equal(got_s, sc1), 'sharded scoring differs from the unsharded call'
     assert np.array_equal(res[1][6], idi) and np.array_equal(res[1][4], idu)      # every rank holds the full result
+
+
+@pytest.mark.parametrize('variant', ['ms-uint64-strings', 'seconds-codes', 'arrow-table', 'datetime'])
+def test_device_frame_to_events_equals_numpy_path(gpu_device, variant):
+    """Section 8 f2: the device ingest (type-string map, ms -> s, stable (session, ts) radix sort, CSR offsets; include/
+    otto_events.h) against the NumPy path (`events.frame_to_events`: lexsort) on SHUFFLED frames in the raw schemas the
+    reference holds (`dataset_writer_pickle.py:29-33, 57-60`: uint64 ms + type strings; splits: seconds + codes).
+    Identical SoA, CSR, session ids and permutation; ties on (session, ts) keep their input order."""
+    import pyarrow as pa
+    from otto_amd.events import frame_to_events, frame_to_events_device
+    from otto_amd.synth import generate_sessions
+    ev = generate_sessions(6000, n_aids=3000, seed=12)
+    fr = ev.to_frame()
+    fr['session'] = fr['session'] * 7 + 11_000_000                   # sparse session ids in the test split's range
+    rng = np.random.default_rng(4)
+    fr['ts'] = (fr['ts'] // 40) * 40                                  # many equal timestamps inside a session: ties
+    fr = fr.iloc[rng.permutation(len(fr))].reset_index(drop=True)
+    if variant in ('ms-uint64-strings', 'arrow-table'):
+        fr['ts'] = fr['ts'].to_numpy().astype(np.uint64) * np.uint64(1000) + rng.integers(0, 1000, len(fr)).astype(np.uint64)
+        fr['type'] = np.array(['clicks', 'carts', 'orders'])[fr['type'].to_numpy()]
+        fr['session'], fr['aid'] = fr['session'].astype(np.uint32), fr['aid'].astype(np.uint32)
+    elif variant == 'datetime':
+        fr['ts'] = pd.to_datetime(fr['ts'], unit='s')
+    want, want_ids = frame_to_events(fr)
+    src = pa.Table.from_pandas(fr, preserve_index=False) if variant == 'arrow-table' else fr
+    got = frame_to_events_device(src, device=gpu_device)
+    host = got.to_host()
+    assert got.n_sessions == want.n_sessions == 6000 and got.n_aids == want.n_aids
+    assert np.array_equal(host.sess_off, want.sess_off) and np.array_equal(got.session_ids.cpu().numpy(), want_ids)
+    assert np.array_equal(host.aid, want.aid) and np.array_equal(host.ts, want.ts) and np.array_equal(host.type, want.type)
+    ts_s = fr['ts'].to_numpy()
+    ts_s = ts_s.astype('datetime64[s]').astype(np.int64) if variant == 'datetime' else ts_s.astype(np.int64) // (1000 if 'ms' in variant or variant == 'arrow-table' else 1)
+    order = np.lexsort((ts_s, fr['session'].to_numpy().astype(np.int64)))
+    assert np.array_equal(got.order.cpu().numpy().view(np.uint32), order.astype(np.uint32))
+
+
+def test_device_ingest_rejects_unknown_type_strings_and_handles_empty(gpu_device):
+    from otto_amd import _lib
+    from otto_amd.events import frame_to_events_device
+    fr = pd.DataFrame({'session': np.array([1, 1], dtype=np.uint32), 'aid': np.array([5, 6], dtype=np.uint32),
+                       'ts': np.array([1_659_304_800_000, 1_659_304_801_000], dtype=np.uint64), 'type': ['clicks', 'wishlist']})
+    with pytest.raises(_lib.OttoError, match='none of clicks'):
+        frame_to_events_device(fr, device=gpu_device)
+    empty = frame_to_events_device(fr.iloc[:0], device=gpu_device)
+    assert empty.n_events == 0 and empty.n_sessions == 0
