@@ -95,6 +95,11 @@ SIGNATURES = {
     'otto_events_sort_workspace': (_i64, [_i64]),
     'otto_events_sort': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _p_i64, _vp, _i64, _vp]),
     'otto_events_type_from_strings': (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
+    # include/otto_pairs.h
+    'otto_pairs_raw_count': (_i32, [_vp, _i64, _i32, _p_i64, _vp]),
+    'otto_pairs_workspace': (_i64, [_i64]),
+    'otto_pairs_time': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _p_i64, _vp, _i64, _vp]),
+    'otto_pairs_diff': (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _p_i64, _vp, _i64, _vp]),
     # include/otto_mf.h
     'otto_mf_create': (_i32, [C.POINTER(_vp), _i64, _i64, _i32, _i64, _i32]),
     'otto_mf_destroy': (None, [_vp]),

@@ -195,6 +195,74 @@ __global__ void k_type_strings(const OFF* off, const uint8_t* bytes, int64_t n, 
 
 using namespace otto;
 
+// the LSD passes over (w.key[cur], w.idx[cur]); digits that are constant over the input (bits clear in `varying`) are skipped
+static int radix_passes(const SortWs& w, int64_t n, uint64_t varying, int* cur_io, hipStream_t s) {
+    const int64_t nb = rs_blocks(n);
+    int cur = *cur_io;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 8 * pass;
+        if (((varying >> shift) & 255ull) == 0) continue;       // constant digit: the pass would be the identity
+        k_rs_hist<<<(unsigned)nb, RS_THREADS, 0, s>>>(w.key[cur], n, shift, nb, w.counts);
+        OTTO_HIP(hipGetLastError());
+        OTTO_TRY(device_scan(CountAt{w.counts}, 256 * nb, w.offs, w.partial, s));
+        k_rs_scatter<<<(unsigned)nb, RS_THREADS, 0, s>>>(w.key[cur], w.idx[cur], n, shift, nb, w.offs, w.key[cur ^ 1], w.idx[cur ^ 1]);
+        OTTO_HIP(hipGetLastError());
+        cur ^= 1;
+    }
+    *cur_io = cur;
+    return 0;
+}
+
+namespace otto {
+__global__ __launch_bounds__(256) void k_orand(const uint64_t* key, int64_t n, unsigned long long* orand) {
+    __shared__ unsigned long long s_or[4], s_and[4];
+    unsigned long long vo = 0, va = ~0ull;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint64_t k = key[i];
+        vo |= k;
+        va &= k;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        vo |= __shfl_xor(vo, o, 64);
+        va &= __shfl_xor(va, o, 64);
+    }
+    if (lane_id() == 0) { s_or[threadIdx.x >> 6] = vo; s_and[threadIdx.x >> 6] = va; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicOr(&orand[0], s_or[0] | s_or[1] | s_or[2] | s_or[3]);
+        atomicAnd(&orand[1], s_and[0] & s_and[1] & s_and[2] & s_and[3]);
+    }
+}
+}  // namespace otto
+
+// Stable sort of n (key u64, value u32) pairs by key, in the workspace of otto_events_sort_workspace(n): on return
+// *d_keys_sorted / *d_vals_sorted point INTO the workspace. Shared with the aid-pair builders (otto_pairs.hip).
+int otto_sort_pairs_in_ws(uint64_t* d_keys /* = ws key[0] */, int64_t n, void* d_ws, uint64_t** d_keys_sorted,
+                          uint32_t** d_vals_sorted, hipStream_t s) {
+    SortWs w;
+    ws_layout(n, (char*)d_ws, &w);
+    OTTO_REQUIRE(d_keys == w.key[0], "keys must have been written into the workspace's first key buffer");
+    unsigned long long init[2] = {0ull, ~0ull};
+    OTTO_HIP(hipMemcpyAsync(w.orand, init, sizeof init, hipMemcpyHostToDevice, s));
+    const int grid = (int)((n + 255) / 256 < 256 * 16 ? (n + 255) / 256 : 256 * 16);
+    k_orand<<<grid, 256, 0, s>>>(w.key[0], n, w.orand);
+    OTTO_HIP(hipGetLastError());
+    unsigned long long h[2];
+    OTTO_HIP(hipMemcpyAsync(h, w.orand, sizeof h, hipMemcpyDeviceToHost, s));
+    OTTO_HIP(hipStreamSynchronize(s));
+    int cur = 0;
+    OTTO_TRY(radix_passes(w, n, h[0] ^ h[1], &cur, s));
+    *d_keys_sorted = w.key[cur];
+    *d_vals_sorted = w.idx[cur];
+    return 0;
+}
+// pointers of the first (key, value) buffers and the scan scratch inside a sort workspace
+void otto_sort_ws_buffers(int64_t n, void* d_ws, uint64_t** key0, uint32_t** val0, uint64_t** scan_out, uint64_t** scan_partial) {
+    SortWs w;
+    ws_layout(n, (char*)d_ws, &w);
+    *key0 = w.key[0]; *val0 = w.idx[0]; *scan_out = w.offs; *scan_partial = w.partial;
+}
+
 extern "C" int64_t otto_events_sort_workspace(int64_t n) {
     if (n <= 0) return 256;
     return (int64_t)ws_layout(n, nullptr, nullptr);
@@ -230,16 +298,7 @@ extern "C" int otto_events_sort(const uint32_t* d_session, const int64_t* d_ts, 
     OTTO_REQUIRE(h[2] == 0, "%llu timestamps are negative or beyond 2^31 - 1 seconds after dividing by %lld", h[2], (long long)ts_div);
     const uint64_t varying = h[0] ^ h[1];                       // bits that differ somewhere in the input
     int cur = 0;
-    for (int pass = 0; pass < 8; ++pass) {
-        const int shift = 8 * pass;
-        if (((varying >> shift) & 255ull) == 0) continue;       // constant digit: the pass would be the identity
-        k_rs_hist<<<(unsigned)nb, RS_THREADS, 0, s>>>(w.key[cur], n, shift, nb, w.counts);
-        OTTO_HIP(hipGetLastError());
-        OTTO_TRY(device_scan(CountAt{w.counts}, 256 * nb, w.offs, w.partial, s));
-        k_rs_scatter<<<(unsigned)nb, RS_THREADS, 0, s>>>(w.key[cur], w.idx[cur], n, shift, nb, w.offs, w.key[cur ^ 1], w.idx[cur ^ 1]);
-        OTTO_HIP(hipGetLastError());
-        cur ^= 1;
-    }
+    OTTO_TRY(radix_passes(w, n, varying, &cur, s));
     OTTO_TRY(device_scan(HeadFlag{w.key[cur]}, n, w.offs, w.partial, s));
     k_emit_sorted<<<grid, 256, 0, s>>>(w.key[cur], w.idx[cur], n, d_aid, d_type, w.offs, d_out_aid, d_out_ts, d_out_type, d_out_order,
                                        d_sess_off, d_sess_id);

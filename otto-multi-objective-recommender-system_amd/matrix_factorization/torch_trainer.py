@@ -28,7 +28,7 @@ if __package__ in (None, ''):   # run as a script from its own directory, like t
 
 from .. import settings
 from . import torch_modules, torch_utils, torch_optim, metrics, visualization
-from .data import DeviceBatchLoader, build_aid_pairs, build_sessions_aids
+from .data import DeviceBatchLoader, build_aid_pairs, build_aid_pairs_device, build_sessions_aids  # noqa: F401
 from .torch_optim import loss_kind
 
 
@@ -140,9 +140,15 @@ def run(config, df=None):
             df = pd.concat((pd.read_pickle(settings.DATA / 'train.pkl'), pd.read_pickle(settings.DATA / 'test.pkl')),
                            axis=0, ignore_index=True)
         if cls == 'CollaborativeFiltering':
-            ds = build_aid_pairs(df, config['dataset']['sampling_strategy'], config['dataset']['chunk_size'],
-                                 config['dataset']['hour_difference'], config['dataset']['target_aggregation'],
-                                 seed=config['training']['random_state'])
+            # sort, self-join / shift-shuffle, de-duplication and per-pair aggregation on the device (include/otto_events.h,
+            # include/otto_pairs.h); only the finished (x1, x2, target) rows come back for the parquet file
+            from ..events import frame_to_events_device
+            dsc = config['dataset']
+            ev = frame_to_events_device(df, device=config['training']['device'])
+            x1, x2, tg = build_aid_pairs_device(ev, dsc['sampling_strategy'], dsc.get('hour_difference', 1),
+                                                dsc.get('target_aggregation', 'mean'), seed=config['training']['random_state'])
+            ds = pd.DataFrame({'x1': x1.cpu().numpy(), 'x2': x2.cpu().numpy(), 'target': tg.cpu().numpy()})
+            del ev, x1, x2, tg
         else:
             ds = build_sessions_aids(df)
         ds.to_parquet(root / fname)

@@ -357,3 +357,41 @@ def test_device_ingest_rejects_unknown_type_strings_and_handles_empty(gpu_device
         frame_to_events_device(fr, device=gpu_device)
     empty = frame_to_events_device(fr.iloc[:0], device=gpu_device)
     assert empty.n_events == 0 and empty.n_sessions == 0
+
+
+def test_device_aid_pair_builders_equal_host_builders(gpu_device):
+    """Section 8 a6: `build_aid_pairs_device` ('time': session self-join + time predicate + per-pair mean / max; 'diff':
+    next-aid positives / shuffled-aid negatives, de-duplicated, positives win) against the host restatement of
+    `torch_trainer.py:190-255` on the same events -- same set of labelled pairs (rows sorted by (x1, x2) before comparing;
+    the consumer shuffles them anyway). 'time' with the full sample (the reference's row sample is unseeded) and, for 'diff',
+    the same shuffle keys on both sides."""
+    from otto_amd.events import frame_to_events_device
+    from otto_amd.matrix_factorization.data import build_aid_pairs, build_aid_pairs_device
+    from otto_amd.synth import generate_sessions
+    ev = generate_sessions(1500, n_aids=300, seed=21)
+    fr = ev.to_frame()
+    dev_ev = frame_to_events_device(fr, device=gpu_device, n_aids=300)
+
+    def rows(t):
+        a = np.stack([np.asarray(c, dtype=np.int64) for c in t], 1)
+        return a[np.lexsort((a[:, 1], a[:, 0]))]
+    for agg in ('mean', 'max'):
+        want = build_aid_pairs(fr, 'time', chunk_size=10 ** 9, hour_difference=1, target_aggregation=agg, sample_frac=1.0)
+        got = build_aid_pairs_device(dev_ev, 'time', hour_difference=1, target_aggregation=agg, sample_frac=1.0)
+        g = rows([c.cpu().numpy() for c in got])
+        w = rows([want['x1'], want['x2'], want['target']])
+        assert g.shape == w.shape and np.array_equal(g, w), agg
+        assert 0 < g[:, 2].mean() < 1
+    keys = np.random.default_rng(3).integers(0, 2 ** 31, ev.n_events, dtype=np.uint64)
+    keys[::5] = keys[1::5][:len(keys[::5])]                       # equal keys: the permutation must stay stable
+    want = build_aid_pairs(fr, 'diff', shuffle_keys=keys)
+    got = build_aid_pairs_device(dev_ev, 'diff', shuffle_keys=keys)
+    g = rows([c.cpu().numpy() for c in got])
+    w = rows([want['x1'], want['x2'], want['target']])
+    assert g.shape == w.shape and np.array_equal(g, w)
+    # a sampled 'time' build is a subset of the pairs of the full one and deterministic in the seed
+    a = build_aid_pairs_device(dev_ev, 'time', sample_frac=0.3, seed=5)
+    b = build_aid_pairs_device(dev_ev, 'time', sample_frac=0.3, seed=5)
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and 0 < a[0].numel() < g.shape[0] * 10
+    with pytest.raises(ValueError):
+        build_aid_pairs_device(dev_ev, 'nope')
