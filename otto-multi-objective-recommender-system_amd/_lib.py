@@ -100,6 +100,9 @@ SIGNATURES = {
     'otto_pairs_workspace': (_i64, [_i64]),
     'otto_pairs_time': (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _p_i64, _vp, _i64, _vp]),
     'otto_pairs_diff': (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _p_i64, _vp, _i64, _vp]),
+    # include/otto_inter.h
+    'otto_inter_workspace': (_i64, [_u32]),
+    'otto_inter_features': (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _u32, _vp, _vp, _vp, _vp, _i64, _vp]),
     # include/otto_mf.h
     'otto_mf_create': (_i32, [C.POINTER(_vp), _i64, _i64, _i32, _i64, _i32]),
     'otto_mf_destroy': (None, [_vp]),

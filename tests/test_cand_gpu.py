@@ -90,3 +90,47 @@ def test_recency_weighted_candidates_match_reference_loop(gpu_device):
             assert n[s] == len(wa), f'session {s}: {n[s]} unique aids vs {len(wa)}'
             assert cand[c, lo:lo + n[s]].tolist() == wa, f'session {s} curve {c}: order differs'
             np.testing.assert_allclose(w[c, lo:lo + n[s]], np.array(ww), rtol=1e-12, atol=0)
+
+
+def test_interaction_features_match_oracle(gpu_device):
+    """Section 8 f4: the (session, candidate) interaction features of `src/ranker/interaction_feature_engineering.py:56-113`
+    from the device candidate arrays against the pandas restatement `oracle/inter_oracle.py` (parity unpinned: polars is
+    not installable here). Integer features bit-exact; float32 means / std within 1e-5 relative (float64 accumulation on
+    both sides, atomics reorder the per-aid sums); NaN where the reference holds a null."""
+    import pandas as pd
+    import torch
+    import inter_oracle as io
+    from otto_amd.ranker import interaction_feature_engineering as ife
+    ev = generate_sessions(1500, n_aids=500, seed=17)
+    rng = np.random.default_rng(2)
+    S, Cn = ev.n_sessions, 100
+    cand = np.full((S, Cn), -1, dtype=np.int32)
+    score = np.zeros((S, Cn), dtype=np.float32)
+    for s in range(S):
+        n = int(rng.integers(0, Cn + 1)) if s % 50 else 1          # some one-candidate sessions (std = null), empty rows
+        # candidates: a mix of the session's own aids and others
+        own = np.unique(ev.aid[ev.sess_off[s]:ev.sess_off[s + 1]])
+        pool = np.unique(np.r_[own, rng.integers(0, ev.n_aids, 2 * Cn)])
+        pick = rng.permutation(pool)[:n]
+        cand[s, :len(pick)] = pick
+        score[s, :len(pick)] = rng.integers(1, 9, len(pick))
+    t = lambda a: torch.from_numpy(a).to(gpu_device)
+    row, sf, af = ife.interaction_features(t(ev.aid.astype(np.int32)), t(ev.type), t(ev.sess_off), t(cand), t(score), ev.n_aids)
+    got = ife.to_frame(np.arange(S), t(cand), t(score), row, sf, af)
+    keep = cand >= 0
+    s_idx, _ = np.nonzero(keep)
+    want = io.interaction_features(pd.DataFrame({'session': s_idx.astype(np.int32), 'candidates': cand[keep], 'candidate_scores': score[keep]}),
+                                   ev.to_frame())
+    key = ['session', 'candidates']
+    got = got.sort_values(key).reset_index(drop=True)
+    want = want.sort_values(key).reset_index(drop=True)
+    assert len(got) == len(want) and (got[key].to_numpy() == want[key].to_numpy()).all()
+    for col in ife.ROW_COLUMNS + ife.SESSION_COLUMNS + ife.AID_COLUMNS:
+        g, w = got[col].to_numpy().astype(np.float64), want[col].to_numpy().astype(np.float64)
+        assert np.array_equal(np.isnan(g), np.isnan(w)), col
+        ok = ~np.isnan(w)
+        if col.endswith(('_sum', '_max', '_min', 'occurrence_count', 'cumcount_last')) and 'score' not in col:
+            assert np.array_equal(g[ok], w[ok]), col
+        else:
+            np.testing.assert_allclose(g[ok], w[ok].astype(np.float32), rtol=1e-5, atol=1e-6, err_msg=col)
+    assert np.isnan(got['session_candidate_score_std']).any() and np.isnan(got['session_candidate_cumcount_last']).any()
