@@ -24,6 +24,10 @@ import numpy as np
 CLICK_RECIPE = (('time_weighted', 'U'), ('click_weighted', 'CC'), ('cart_weighted', 'CC'), ('click_cart', 'CC'), ('cart_order', 'CC'))
 CART_RECIPE = (('time_weighted', 'U'), ('cart_weighted', 'CC'), ('cart_order', 'CC'))
 ORDER_RECIPE = CART_RECIPE
+# recipes of the standalone model, src/covisitation/inference.py:227,231,235 -- 'neighbours' = the fastText / Annoy
+# neighbours of the session's LAST aid (:223-224), here one more {aid: [45 neighbours]} dict
+INFERENCE_CLICK_RECIPE = CLICK_RECIPE + (('neighbours', 'LAST'),)
+INFERENCE_CART_RECIPE = CART_RECIPE + (('neighbours', 'LAST'),)
 
 
 def matrix_to_dict(y, n):
@@ -40,6 +44,7 @@ def session_candidates(session_aids, session_event_types, top, recipe, n_common=
         'U': session_unique_aids,
         'CC': np.unique(aids[types <= 1]).tolist(),
         'CO': np.unique(aids[types >= 1]).tolist(),
+        'LAST': session_aids[-1:],
     }
     covisited = []
     for kind, src in recipe:
@@ -55,3 +60,11 @@ def all_candidates(aid, typ, sess_off, top, recipe, n_common=100):
         lo, hi = int(sess_off[s]), int(sess_off[s + 1])
         res.append(session_candidates(aid[lo:hi], typ[lo:hi], top, recipe, n_common))
     return res
+
+
+def session_predictions(session_aids, sorted_aids, most_frequent, n_pred=20):
+    """src/covisitation/inference.py:236-237 (and :238-241 for carts / orders)."""
+    session_unique_aids = list(dict.fromkeys(list(map(int, session_aids))[::-1]))
+    predictions = session_unique_aids + sorted_aids[:n_pred - len(session_unique_aids)]
+    predictions = predictions + most_frequent[:n_pred - len(predictions)]
+    return predictions

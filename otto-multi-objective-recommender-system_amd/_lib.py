@@ -35,6 +35,7 @@ class CandParams(C.Structure):
         ('term_matrix', C.c_int32 * 8),
         ('term_source', C.c_int32 * 8),
         ('n_common', C.c_int32),
+        ('mat_k', C.c_int32 * 8),
     ]
 
 
@@ -90,6 +91,7 @@ SIGNATURES = {
     'otto_debug_calibrate': (_i32, [_vp, _i64, _i32, _vp]),
     # include/otto_cand.h
     'otto_cand_lookup': (_i32, [C.POINTER(CandParams), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    'otto_cand_predictions': (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     'otto_recency_candidates': (_i32, [C.POINTER(RecencyParams), _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     # include/otto_events.h
     'otto_events_sort_workspace': (_i64, [_i64]),

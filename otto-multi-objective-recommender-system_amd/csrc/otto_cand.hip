@@ -51,8 +51,8 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
     __shared__ uint32_t s_aid[CD_MAXL];
     __shared__ uint8_t s_ty[CD_MAXL];
     __shared__ uint8_t s_flag[CD_MAXL];               // bit0 last occurrence, bit1 first click/cart, bit2 first cart/order
-    __shared__ uint32_t s_src[3][CD_MAXL];
-    __shared__ uint32_t s_nsrc[3];
+    __shared__ uint32_t s_src[4][CD_MAXL];            // U, CC, CO, LAST (the last event's aid: a single source)
+    __shared__ uint32_t s_nsrc[4];
     __shared__ uint32_t s_base[CD_MAXQ];               // position of list q in the concatenation | len << 24
     __shared__ unsigned long long s_tab[CD_T];        // aid << 32 | count
     __shared__ uint32_t s_fp[CD_T];                    // first position
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
         // ---- A ----------------------------------------------------------------------------------------
         for (int i = tid; i < n; i += CD_THREADS) { s_aid[i] = a.aid[lo + i]; s_ty[i] = a.type[lo + i]; }
         if (tid < 3) s_nsrc[tid] = 0;
+        if (tid == 3) { s_nsrc[3] = n > 0 ? 1u : 0u; s_src[3][0] = n > 0 ? a.aid[lo + n - 1] : 0u; }
         for (int i = tid; i < NC; i += CD_THREADS) s_sel[i] = 0;
         __syncthreads();
         for (int i = tid; i < n; i += CD_THREADS) {
@@ -122,8 +123,10 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
 #pragma unroll
                 for (int u = 1; u < OTTO_CAND_MAX_TERMS; ++u) t += (q >= tstart[u]) ? 1 : 0;
                 const uint32_t x = s_src[a.p.term_source[t]][q - tstart[t]];
-                const int32_t ln = x < a.p.n_aids ? a.p.d_mat_n[a.p.term_matrix[t]][x] : 0;
-                len = ln < 0 ? 0u : (uint32_t)(ln > K ? K : ln);
+                const int m = a.p.term_matrix[t];
+                const int Km = a.p.mat_k[m] > 0 ? a.p.mat_k[m] : K;
+                const int32_t ln = x < a.p.n_aids ? a.p.d_mat_n[m][x] : 0;
+                len = ln < 0 ? 0u : (uint32_t)(ln > Km ? Km : ln);
             }
             uint32_t tot;
             const uint32_t off = block_excl_scan<uint32_t, CD_THREADS>(len, s_scan, &tot);
@@ -155,12 +158,13 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
             for (uint32_t q = hw; q < Q; q += CD_THREADS / 32) {
                 const uint32_t b = s_base[q];
                 const uint32_t len = b >> 24, base = b & 0xFFFFFFu;
-                if ((uint32_t)l < len) {
+                for (uint32_t l2 = (uint32_t)l; l2 < len; l2 += 32u) {      // lists longer than 32 (neighbour lists): two rounds
                     int t = 0;
 #pragma unroll
                     for (int u = 1; u < OTTO_CAND_MAX_TERMS; ++u) t += (q >= tstart[u]) ? 1 : 0;
                     const uint32_t x = s_src[a.p.term_source[t]][q - tstart[t]];
-                    const uint32_t y = (uint32_t)a.p.d_mat_y[a.p.term_matrix[t]][(size_t)x * K + l];
+                    const int m = a.p.term_matrix[t];
+                    const uint32_t y = (uint32_t)a.p.d_mat_y[m][(size_t)x * (a.p.mat_k[m] > 0 ? a.p.mat_k[m] : K) + l2];
                     const uint32_t h = y * 0x9E3779B1u;
                     if (lgR == 0 || ((h >> (32 - lt - lgR)) & (R - 1u)) == part) {
                         uint32_t slot = h >> (32 - lt);
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
                             const bool fresh = old == CD_EMPTY;
                             if (fresh || (uint32_t)(old >> 32) == y) {
                                 if (!fresh) atomicAdd(&s_tab[slot], 1ull);
-                                atomicMin(&s_fp[slot], base + (uint32_t)l);
+                                atomicMin(&s_fp[slot], base + l2);
                                 placed = true;
                                 break;
                             }
@@ -304,6 +308,46 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
     }
 }
 
+// final predictions: unique session aids (most recent first) + candidates + global most frequent aids
+__global__ __launch_bounds__(64) void k_predictions(const uint32_t* aid, const int64_t* off, int64_t n_sess, const int32_t* cand,
+                                                   const int32_t* n_cand, int n_common, const int32_t* freq, int n_freq, int n_pred,
+                                                   int32_t* pred, int32_t* n_out) {
+    const unsigned lane = lane_id();
+    for (int64_t s = blockIdx.x; s < n_sess; s += gridDim.x) {
+        const int64_t lo = off[s], hi = off[s + 1];
+        int filled = 0;
+        // walk the session backwards, 64 events at a time; an event enters if no LATER event holds its aid
+        for (int64_t top = hi; top > lo && filled < n_pred; top -= 64) {
+            const int64_t i = top - 1 - (int64_t)lane;
+            bool first = false;
+            uint32_t x = 0;
+            if (i >= lo) {
+                x = aid[i];
+                first = true;
+                for (int64_t j = i + 1; j < hi; ++j)
+                    if (aid[j] == x) { first = false; break; }
+            }
+            const uint64_t m = __ballot(first);
+            const int pos = filled + (int)__popcll(m & ((1ull << lane) - 1ull));
+            if (first && pos < n_pred) pred[s * n_pred + pos] = (int32_t)x;
+            filled += (int)__popcll(m);
+        }
+        if (filled > n_pred) filled = n_pred;
+        const int nu = filled;
+        // candidates (the session's aids are already removed from them): [:n_pred - len(unique)]
+        const int nc = n_cand[s] < n_common ? n_cand[s] : n_common;
+        const int take = nc < n_pred - nu ? nc : n_pred - nu;
+        if ((int)lane < take) pred[s * n_pred + nu + lane] = cand[s * n_common + lane];
+        filled += take > 0 ? take : 0;
+        // global most frequent aids: [:n_pred - len(predictions)] -- NOT de-duplicated against the row (as in the reference)
+        const int rest = n_pred - filled < n_freq ? n_pred - filled : n_freq;
+        if ((int)lane < rest) pred[s * n_pred + filled + lane] = freq[lane];
+        filled += rest > 0 ? rest : 0;
+        for (int p = filled + (int)lane; p < n_pred; p += 64) pred[s * n_pred + p] = -1;
+        if (lane == 0) n_out[s] = filled;
+    }
+}
+
 // ---- recency-weighted candidates (section 8 f3) ------------------------------------------------------------------
 struct RecencyArgs {
     otto_recency_params p;
@@ -430,13 +474,14 @@ extern "C" int otto_cand_lookup(const otto_cand_params* p, const uint32_t* d_aid
     OTTO_REQUIRE(p && d_sess_off && d_cand && d_count && d_n, "otto_cand_lookup: null argument");
     OTTO_REQUIRE(p->n_aids > 0 && p->n_aids <= (1u << 26), "n_aids must be in [1, 2^26]");
     OTTO_REQUIRE(p->k >= 1 && p->k <= 32, "k must be in [1, 32]");
+    for (int m = 0; m < p->n_matrices; ++m) OTTO_REQUIRE(p->mat_k[m] >= 0 && p->mat_k[m] <= 64, "mat_k[%d] must be in [0, 64]", m);
     OTTO_REQUIRE(p->n_matrices >= 1 && p->n_matrices <= OTTO_CAND_MAX_MATRICES, "n_matrices out of range");
     OTTO_REQUIRE(p->n_terms >= 1 && p->n_terms <= OTTO_CAND_MAX_TERMS, "n_terms out of range");
     OTTO_REQUIRE(p->n_common >= 1 && p->n_common <= OTTO_CAND_MAX_COMMON, "n_common must be in [1, 128]");
     for (int m = 0; m < p->n_matrices; ++m) OTTO_REQUIRE(p->d_mat_y[m] && p->d_mat_n[m], "matrix %d is null", m);
     for (int t = 0; t < p->n_terms; ++t) {
         OTTO_REQUIRE(p->term_matrix[t] >= 0 && p->term_matrix[t] < p->n_matrices, "term %d: bad matrix", t);
-        OTTO_REQUIRE(p->term_source[t] >= 0 && p->term_source[t] <= 2, "term %d: bad source", t);
+        OTTO_REQUIRE(p->term_source[t] >= 0 && p->term_source[t] <= OTTO_CAND_SRC_LAST, "term %d: bad source", t);
     }
     if (n_sess <= 0) return 0;
     OTTO_REQUIRE(d_aid && d_type, "null event arrays");
@@ -463,5 +508,18 @@ extern "C" int otto_cand_lookup(const otto_cand_params* p, const uint32_t* d_aid
     (void)hipFree(d_err);
     OTTO_REQUIRE(le == hipSuccess && ce == hipSuccess && se == hipSuccess, "k_cand failed: %s", hipGetErrorString(le != hipSuccess ? le : (ce != hipSuccess ? ce : se)));
     OTTO_REQUIRE(err == 0, "%u session(s) longer than %d events", err, OTTO_CAND_MAX_SESSION);
+    return 0;
+}
+
+extern "C" int otto_cand_predictions(const uint32_t* d_aid, const int64_t* d_sess_off, int64_t n_sess, const int32_t* d_cand,
+                                     const int32_t* d_n_cand, int32_t n_common, const int32_t* d_frequent, int32_t n_frequent,
+                                     int32_t n_pred, int32_t* d_pred, int32_t* d_n_pred, void* stream) {
+    OTTO_REQUIRE(n_sess >= 0 && n_pred >= 1 && n_pred <= 64 && n_common >= 1 && n_common <= 64 && n_frequent >= 0 && n_frequent <= 64,
+                 "n_pred, n_common must be in [1, 64], n_frequent in [0, 64]");
+    if (n_sess == 0) return 0;
+    OTTO_REQUIRE(d_aid && d_sess_off && d_cand && d_n_cand && d_pred && d_n_pred && (d_frequent || n_frequent == 0), "otto_cand_predictions: null argument");
+    k_predictions<<<(unsigned)(n_sess < 256 * 64 ? n_sess : 256 * 64), 64, 0, (hipStream_t)stream>>>(
+        d_aid, d_sess_off, n_sess, d_cand, d_n_cand, n_common, d_frequent, n_frequent, n_pred, d_pred, d_n_pred);
+    OTTO_HIP(hipGetLastError());
     return 0;
 }

@@ -134,3 +134,34 @@ def test_interaction_features_match_oracle(gpu_device):
         else:
             np.testing.assert_allclose(g[ok], w[ok].astype(np.float32), rtol=1e-5, atol=1e-6, err_msg=col)
     assert np.isnan(got['session_candidate_score_std']).any() and np.isnan(got['session_candidate_cumcount_last']).any()
+
+
+def test_inference_recipes_with_neighbour_term_and_final_predictions(gpu_device):
+    """The standalone model's loop (`src/covisitation/inference.py:204-247`): the covisitation lists + the 45 nearest
+    neighbours of the session's LAST aid (a [n_aids, 45] matrix here; fastText + Annoy in the reference, :223-224),
+    `most_common(20)` without the session's aids, then session aids + candidates + the global top-20, cut at 20. Candidates,
+    counts and final prediction rows identical to the oracle's stdlib loop."""
+    import torch
+    from otto_amd.covisitation import candidates as cd
+    ev = generate_sessions(1200, n_aids=600, seed=33)
+    mats = dict(_matrices(ev, gpu_device, k=15))
+    rng = np.random.default_rng(8)
+    nb = np.stack([rng.permutation(ev.n_aids)[:45] for _ in range(ev.n_aids)]).astype(np.int32)      # stand-in neighbour table
+    nb_n = rng.integers(0, 46, ev.n_aids).astype(np.int32)
+    nb_n[::7] = 45
+    mats['neighbours'] = (torch.from_numpy(nb).to(gpu_device), None, torch.from_numpy(nb_n).to(gpu_device))
+    top = {kind: cdo.matrix_to_dict(m[0].cpu().numpy(), m[-1].cpu().numpy()) for kind, m in mats.items()}
+    aid = torch.from_numpy(ev.aid.astype(np.int32)).to(gpu_device)
+    typ = torch.from_numpy(ev.type).to(gpu_device)
+    off = torch.from_numpy(ev.sess_off).to(gpu_device)
+    frequent = rng.permutation(ev.n_aids)[:20].tolist()
+    for recipe, orecipe in ((cd.INFERENCE_CLICK_RECIPE, cdo.INFERENCE_CLICK_RECIPE), (cd.INFERENCE_CART_RECIPE, cdo.INFERENCE_CART_RECIPE)):
+        cand, cnt, n = cd.candidate_lookup(aid, typ, off, mats, recipe, n_common=20)
+        pred, npred = cd.predictions(aid, off, cand, n, frequent, n_pred=20)
+        cand, cnt, n, pred, npred = (t.cpu().numpy() for t in (cand, cnt, n, pred, npred))
+        want = cdo.all_candidates(ev.aid, ev.type, ev.sess_off, top, orecipe, 20)
+        for s, (wa, wc) in enumerate(want):
+            assert n[s] == len(wa) and cand[s, :n[s]].tolist() == wa and cnt[s, :n[s]].tolist() == wc, s
+            lo, hi = ev.sess_off[s], ev.sess_off[s + 1]
+            wp = cdo.session_predictions(ev.aid[lo:hi], wa, frequent, 20)[:20]
+            assert npred[s] == len(wp) and pred[s, :npred[s]].tolist() == wp and (pred[s, npred[s]:] == -1).all(), s
