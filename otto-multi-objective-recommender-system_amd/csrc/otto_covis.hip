@@ -900,6 +900,7 @@ struct ReduceArgs {
     const uint32_t* rec;
     const uint32_t* tw;
     const uint64_t* pstart;        // [n_items+1] partition buckets of L items with R > 1 (null: filter mode)
+    const uint32_t* pcursor;       // [n_items] records the scatter put into each bucket
     const uint32_t* prec;
     const uint32_t* ptw;
     int group;
@@ -1090,6 +1091,23 @@ struct PartArgs {
     uint32_t l_cap;
     int window_max;                // largest window (records per run <= window_max - 1)
     int allow_packed;
+    uint32_t* flag;                // [n_aids] bucket overflow (capacity-sized buckets): the aid is redone with exact bucket sizes
+    uint32_t* ovf_count;
+};
+
+// Capacity of a partition bucket when the buckets are sized WITHOUT the count pass: twice the mean partition size + a
+// margin. A partition can exceed it only through one hot aid_y (equal records share a partition); the scatter detects
+// that, flags the aid, and the host redoes the flagged aids with counted buckets.
+__host__ __device__ __forceinline__ uint64_t bucket_cap(uint64_t n_records, int lgR) {
+    return lgR == 0 ? 0ull : 2ull * ((n_records + (1ull << lgR) - 1ull) >> lgR) + 256ull;
+}
+struct ItemCap {     // bucket capacity of L item i
+    const uint64_t* items;
+    const uint64_t* cnt64;
+    __device__ uint64_t operator()(int64_t i) const {
+        const uint64_t item = items[i];
+        return bucket_cap(cnt64[item & REC_AID_MASK] & CNT_REC_MASK, (int)(item >> 50));
+    }
 };
 
 // TW: the time channel travels with the records (GROUP_TIME): staged and scattered alongside
@@ -1102,6 +1120,7 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
     __shared__ uint32_t s_stage[SCATTER ? PART_STAGE : 1];
     __shared__ uint32_t s_stage_tw[(SCATTER && TW) ? PART_STAGE : 1];
     __shared__ uint32_t s_scan[256 / 64 + 1];
+    __shared__ uint32_t s_full;                        // a capacity-sized bucket of this chunk's aid is full
     const int wid = threadIdx.x >> 6;
     for (uint32_t ci = blockIdx.x; ci < a.n_chunks; ci += gridDim.x) {
         const uint64_t ch = a.chunks[ci];
@@ -1115,7 +1134,7 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
         const uint64_t rb = a.run_start[x] + c * PART_CHUNK_RUNS;
         uint64_t re = rb + PART_CHUNK_RUNS;
         if (re > a.run_start[x + 1]) re = a.run_start[x + 1];
-        const bool direct = lgR > (SCATTER ? PART_STAGE_LOG2R : PART_LDS_LOG2R) || (a.cnt64[x] & CNT_REC_MASK) >= (1ull << 32) ||
+        const bool direct = lgR > (SCATTER ? PART_STAGE_LOG2R : PART_LDS_LOG2R) || (a.cnt64[x] & CNT_REC_MASK) >= (1ull << 31) ||
                             (SCATTER && a.window_max * PART_CHUNK_RUNS > PART_STAGE);
         if (direct) {
             // no LDS staging (giant aids, or the time channel travels along): global cursor per record
@@ -1124,13 +1143,18 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
                 if (!SCATTER) atomicAdd(&a.pcount[g], 1u);
                 else {
                     const uint64_t pos = a.pstart[g] + atomicAdd(&a.pcursor[g], 1u);
-                    a.prec[pos] = rc;
-                    if (a.ptw) a.ptw[pos] = a.tw[slot];
+                    if (pos >= a.pstart[g + 1]) {                      // capacity-sized bucket is full
+                        if (atomicExch(&a.flag[x], 1u) == 0u) atomicAdd(a.ovf_count, 1u);
+                    } else {
+                        a.prec[pos] = rc;
+                        if (a.ptw) a.ptw[pos] = a.tw[slot];
+                    }
                 }
             });
             continue;
         }
         for (uint32_t p = threadIdx.x; p < R; p += 256) s_cnt[p] = 0;
+        if (threadIdx.x == 0) s_full = 0;
         __syncthreads();
         for_each_record<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t) {
             atomicAdd(&s_cnt[(rec_hash(rc) >> pshift) & pmask], 1u);
@@ -1159,7 +1183,11 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
                 const uint32_t p = threadIdx.x * PPT + q;
                 if (p < R) {
                     uint32_t gpos = 0;
-                    if (cnt[q]) gpos = (uint32_t)(a.pstart[g0 + p] - x_base) + atomicAdd(&a.pcursor[g0 + p], cnt[q]);
+                    if (cnt[q]) {
+                        const uint32_t old = atomicAdd(&a.pcursor[g0 + p], cnt[q]);
+                        gpos = (uint32_t)(a.pstart[g0 + p] - x_base) + old;
+                        if ((uint64_t)old + cnt[q] > a.pstart[g0 + p + 1] - a.pstart[g0 + p]) s_full = 1u;   // full: nothing of this chunk is written
+                    }
                     s_delta[p] = gpos - off;
                     s_cnt[p] = off;
                     off += cnt[q];
@@ -1173,6 +1201,11 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
                 if (TW) s_stage_tw[(SCATTER && TW) ? pos : 0] = a.tw[slot];
             });
             __syncthreads();
+            if (s_full) {                                              // block-uniform (written before two barriers)
+                if (threadIdx.x == 0 && atomicExch(&a.flag[x], 1u) == 0u) atomicAdd(a.ovf_count, 1u);
+                __syncthreads();
+                continue;
+            }
             // the stage is grouped by partition: consecutive threads write consecutive bucket addresses
             for (uint32_t i = threadIdx.x; i < total; i += 256) {
                 const uint32_t rc = s_stage[i];
@@ -1296,7 +1329,11 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             const uint32_t xx = (uint32_t)(d.item & REC_AID_MASK);
             d.rb = a.run_start[xx];
             d.re = a.run_start[xx + 1];
-            if ((d.item >> 50) != 0 && a.pstart) { d.ps = a.pstart[d.it]; d.pe = a.pstart[d.it + 1]; }
+            if ((d.item >> 50) != 0 && a.pstart) {
+                d.ps = a.pstart[d.it];
+                const uint64_t cap = a.pstart[d.it + 1] - d.ps, got = a.pcursor[d.it];       // a full (flagged) bucket: got > cap
+                d.pe = d.ps + (got < cap ? got : cap);
+            }
         }
     };
     ItemDesc cur, nx;
@@ -2433,6 +2470,8 @@ struct otto_covis_ctx {
     DevBuf litem_start, chunks, pcount, pcursor, pstart, prec, ptw;
     uint64_t n_chunks = 0;
     int partition = 1;
+    bool exact_round = false;      // set by finalize for the rounds that redo flagged aids
+    int part_sized = 1;            // option "part_sized": capacity-sized buckets on the first attempt (no count pass); 0 = always counted
     int debug_skip = 0;
     // reduce scratch
     DevBuf part_y, part_w;
@@ -2883,27 +2922,41 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
             OTTO_TRY(c->pcount.ensure((size_t)a.n_items * 4, 0, s));
             OTTO_TRY(c->pcursor.ensure((size_t)a.n_items * 4, 0, s));
             OTTO_TRY(c->pstart.ensure((size_t)(a.n_items + 1) * 8, 0, s));
-            OTTO_TRY(c->prec.ensure((size_t)(c->bin_pairs[2] ? c->bin_pairs[2] : 1) * 4, 0, s));
-            if (time) OTTO_TRY(c->ptw.ensure((size_t)(c->bin_pairs[2] ? c->bin_pairs[2] : 1) * 4, 0, s));
             OTTO_TRY(c->partial.ensure(scan_partial_bytes((int64_t)a.n_items), 0, s));
-            OTTO_HIP(hipMemsetAsync(c->pcount.p, 0, (size_t)a.n_items * 4, s));
             OTTO_HIP(hipMemsetAsync(c->pcursor.p, 0, (size_t)a.n_items * 4, s));
             PartArgs pa{c->chunks.as<uint64_t>(), (uint32_t)c->n_chunks, c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(),
                         c->run_start.as<uint64_t>(), c->sorted_desc.as<uint64_t>(), c->rec.as<uint32_t>(), c->tw.as<uint32_t>(),
                         c->litem_start.as<uint64_t>(), c->pcount.as<uint32_t>(), c->pcursor.as<uint32_t>(),
-                        c->pstart.as<uint64_t>(), c->prec.as<uint32_t>(), time ? c->ptw.as<uint32_t>() : nullptr, c->l_cap, c->p.window,
-                        a.allow_packed};
+                        c->pstart.as<uint64_t>(), nullptr, nullptr, c->l_cap, c->p.window, a.allow_packed, c->flag.as<uint32_t>(),
+                        c->counters.as<uint32_t>()};
             const uint32_t pgrid = (uint32_t)(c->n_chunks < 256u * 5u ? c->n_chunks : 256u * 5u);
             const uint32_t cgrid = (uint32_t)(c->n_chunks < 256u * 8u ? c->n_chunks : 256u * 8u);
-            kname(c, OTTO_COVIS_T_PARTITION, "k_partition<false> + k_partition<true>");
-            k_partition<false, false><<<cgrid, 256, 0, s>>>(pa);
-            OTTO_HIP(hipGetLastError());
-            OTTO_TRY(device_scan(PCount{c->pcount.as<uint32_t>()}, (int64_t)a.n_items, c->pstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+            // First attempt: buckets sized from the record counts the index already holds (2 x mean + margin), no count pass.
+            // Retry rounds (aids whose bucket or LDS table overflowed): counted buckets, exact.
+            const bool sized = c->part_sized && !c->exact_round;
+            if (sized) {
+                kname(c, OTTO_COVIS_T_PARTITION, "k_partition<true>");
+                OTTO_TRY(device_scan(ItemCap{a.items, c->cnt64.as<uint64_t>()}, (int64_t)a.n_items, c->pstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+            } else {
+                kname(c, OTTO_COVIS_T_PARTITION, "k_partition<false> + k_partition<true>");
+                OTTO_HIP(hipMemsetAsync(c->pcount.p, 0, (size_t)a.n_items * 4, s));
+                k_partition<false, false><<<cgrid, 256, 0, s>>>(pa);
+                OTTO_HIP(hipGetLastError());
+                OTTO_TRY(device_scan(PCount{c->pcount.as<uint32_t>()}, (int64_t)a.n_items, c->pstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+            }
+            uint64_t bucket_total = 0;
+            OTTO_HIP(hipMemcpyAsync(&bucket_total, c->pstart.as<uint64_t>() + a.n_items, 8, hipMemcpyDeviceToHost, s));
+            OTTO_HIP(hipStreamSynchronize(s));
+            OTTO_TRY(c->prec.ensure((size_t)(bucket_total ? bucket_total : 1) * 4, 0, s));
+            if (time) OTTO_TRY(c->ptw.ensure((size_t)(bucket_total ? bucket_total : 1) * 4, 0, s));
+            pa.prec = c->prec.as<uint32_t>();
+            pa.ptw = time ? c->ptw.as<uint32_t>() : nullptr;
             if (time) k_partition<true, true><<<pgrid, 256, 0, s>>>(pa);
             else k_partition<true, false><<<pgrid, 256, 0, s>>>(pa);
             OTTO_HIP(hipGetLastError());
             tend(c, OTTO_COVIS_T_PARTITION, s);
             a.pstart = c->pstart.as<uint64_t>();
+            a.pcursor = c->pcursor.as<uint32_t>();
             a.prec = c->prec.as<uint32_t>();
             a.ptw = c->ptw.as<uint32_t>();
         }
@@ -3026,6 +3079,7 @@ extern "C" int otto_covis_finalize(otto_covis_ctx* c, int group, int k, uint32_t
                 OTTO_TRY(launch_reduce_group(c, a, 0, s));
                 OTTO_TRY(launch_reduce_group(c, a, 1, s));
             }
+            c->exact_round = !first;
             OTTO_TRY(launch_reduce_group(c, a, 2, s));
             uint32_t ovf = 0;
             OTTO_HIP(hipMemcpyAsync(&ovf, c->counters.p, 4, hipMemcpyDeviceToHost, s));
@@ -3059,6 +3113,7 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
     if (strcmp(name, "guess") == 0) { c->guess = value != 0; return 0; }           // threshold guessing on/off (A/B)
     if (strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }           // fused in-order expansion on/off (A/B)
     if (strcmp(name, "fast_path") == 0) { c->fast_path = value != 0; return 0; }   // gap-free window kernel on/off (A/B)
+    if (strcmp(name, "part_sized") == 0) { c->part_sized = value != 0; return 0; }   // A/B: counted buckets only
     if (strcmp(name, "partition") == 0) {
         // 1 (default): bucket heavy aids' records by hash partition once; 0: every partition re-reads
         // all of its aid's records and filters (round-1 baseline, kept for A/B measurements)
