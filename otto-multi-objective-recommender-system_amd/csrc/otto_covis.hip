@@ -400,7 +400,7 @@ __device__ __forceinline__ TaskPre fetch_task(const ExpandArgs& a, const uint4* 
     return p;
 }
 
-template <int G, bool TIME, bool FAST>
+template <int G, bool TIME, bool FAST, bool DBG>
 __device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, uint32_t* xs, unsigned lane, const TaskPre& tp) {
     constexpr int WPW = 64 / G;
     const int n = tp.n;
@@ -453,9 +453,9 @@ __device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, 
             const int dq = __builtin_amdgcn_readlane((int)d1, q * G) + 1;
             dmax = dq > dmax ? dq : dmax;
         }
-        if (a.debug & 2) dmax = 0;
+        if (DBG && (a.debug & 2)) dmax = 0;
         for (int k = 0; k < dmax; ++k) {
-            if (!(a.debug & 1) && rep && (uint32_t)k <= d1 && (uint32_t)k != below) {
+            if (!(DBG && (a.debug & 1)) && rep && (uint32_t)k <= d1 && (uint32_t)k != below) {
                 const uint32_t o = (uint32_t)k * d1 + below - (below > (uint32_t)k ? 1u : 0u);
                 recp[o] = word;
                 if (TIME) twp[o] = xs[w0 + k];
@@ -476,7 +476,7 @@ __device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, 
     const uint32_t nlim = act ? (uint32_t)n : 0u;
     uint32_t done = 0;
     uint4 e = evw[0];
-    if (a.debug & 2) nmax = 0;
+    if (DBG && (a.debug & 2)) nmax = 0;
     // Predicates are kept as wave masks (v_cmp writes them, s_and combines them, exec takes them): the whole wave is
     // active here, so a mask IS the ballot -- no select/compare round trip per ballot.
     constexpr int NE = 33, EQ = 32, ULT = 36, ULE = 37;
@@ -494,7 +494,7 @@ __device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, 
             const uint64_t E = V & ~S & F;                                              // lanes that emit
             const uint64_t D = rep64 & S;                                               // column classes already in the row
             if (__builtin_amdgcn_inverse_ballot_w64(M)) done |= bit;
-            if (__builtin_amdgcn_inverse_ballot_w64(E) && !(a.debug & 1)) {
+            if (__builtin_amdgcn_inverse_ballot_w64(E) && !(DBG && (a.debug & 1))) {
                 const uint32_t o = (e.z >> 5) + (uint32_t)__popcll(D & win64) + (uint32_t)__popcll(E & lw64);
                 recp[o] = word;
                 if (TIME) twp[o] = e.w;
@@ -510,7 +510,8 @@ __device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, 
     wave_lds_sync();
 }
 
-template <bool TIME>
+// DBG: the timing diagnostics of ExpandArgs::debug are compiled into a second instantiation only
+template <bool TIME, bool DBG>
 __global__ __launch_bounds__(256) void k_expand_fused(ExpandArgs a, int64_t n_sess, int use_fast) {
     __shared__ uint4 s_ev[4][64];
     __shared__ uint32_t s_xs[4][TIME ? 64 : 1];
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(256) void k_expand_fused(ExpandArgs a, int64_t n_se
                 TaskPre nx;
                 if (t0 + WPW < c) nx = fetch_task<G, !FAST || TIME>(a, ta, tb, b0, c, t0 + WPW, lane);
                 else nx = fetch_task<GN, !FASTN || TIME>(a, ta, tb, bn, cn, 0, lane);
-                expand_task_reg<G, TIME, FAST>(a, ev, xs, lane, tp);
+                expand_task_reg<G, TIME, FAST, DBG>(a, ev, xs, lane, tp);
                 tp = nx;
             }
             if (c == 0) tp = fetch_task<GN, !FASTN || TIME>(a, ta, tb, bn, cn, 0, lane);
@@ -2610,13 +2611,16 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
         int per_cu = 0, n_cu = 0, dev = 0;
         OTTO_HIP(hipGetDevice(&dev));
         OTTO_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        if (p.want_time) OTTO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_expand_fused<true>, 256, 0));
-        else OTTO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_expand_fused<false>, 256, 0));
+        if (p.want_time) OTTO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_expand_fused<true, false>, 256, 0));
+        else OTTO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_expand_fused<false, false>, 256, 0));
         const int64_t resident = (int64_t)(per_cu > 0 ? per_cu : 4) * (n_cu > 0 ? n_cu : 256);   // one round of resident workgroups
         const int grid = (int)(blocks < resident ? blocks : resident);
         kname(c, OTTO_COVIS_T_EXPAND, "k_expand_fused<%s>", p.want_time ? "true" : "false");
-        if (p.want_time) k_expand_fused<true><<<grid, 256, 0, s>>>(a, n_sess, c->fast_path);
-        else k_expand_fused<false><<<grid, 256, 0, s>>>(a, n_sess, c->fast_path);
+        if (a.debug) {
+            if (p.want_time) k_expand_fused<true, true><<<grid, 256, 0, s>>>(a, n_sess, c->fast_path);
+            else k_expand_fused<false, true><<<grid, 256, 0, s>>>(a, n_sess, c->fast_path);
+        } else if (p.want_time) k_expand_fused<true, false><<<grid, 256, 0, s>>>(a, n_sess, c->fast_path);
+        else k_expand_fused<false, false><<<grid, 256, 0, s>>>(a, n_sess, c->fast_path);
         OTTO_HIP(hipGetLastError());
         tend(c, OTTO_COVIS_T_EXPAND, s);
         c->rec_used += n_slots;
