@@ -1060,6 +1060,66 @@ __device__ __forceinline__ void for_each_record_batch(const uint64_t* sorted_des
     }
 }
 
+// Same visit, packed 8 lanes per SEGMENT (8 consecutive records of a run): a run of len records is ceil(len / 8) segments,
+// the segments of a wave's 64 runs are numbered by a wave scan and dealt to the eight 8-lane groups, so a wave-instruction
+// carries up to 64 records whatever the run lengths are (two 32-lane runs per instruction fill ~40 % of the lanes at the
+// OTTO run-length mix; the consumer's insert rounds -- its cost -- scale with the instructions, not the records).
+// s_seg: 256 bytes of LDS private to the wave (segment -> lane that holds the run's descriptor).
+// NEED_SL: the consumer wants the record's slot (time channel lookup); otherwise the slot arrays are not kept
+template <int NW, int GATHER_U, bool NEED_SL, typename FB>
+__device__ __forceinline__ void for_each_record_seg(const uint64_t* sorted_desc, const uint32_t* rec, uint64_t r0, uint64_t r1,
+                                                    int wid, uint8_t* s_seg, FB fb) {
+    const unsigned lane = lane_id();
+    const uint32_t g = lane >> 3, gl = lane & 7u;
+    if (r0 >= r1) return;
+    auto load_desc = [&](uint64_t cb) {
+        const uint64_t mine = cb + (uint64_t)lane * NW + wid;
+        return mine < r1 ? sorted_desc[mine] : 0ull;
+    };
+    uint64_t d = load_desc(r0);
+    for (uint64_t cb = r0; cb < r1; cb += (uint64_t)NW * 64) {
+        const uint64_t cbn = cb + (uint64_t)NW * 64;
+        const uint64_t dn = cbn < r1 ? load_desc(cbn) : 0ull;              // next descriptors in flight
+        const uint32_t len = (uint32_t)(d & 0xFFull);
+        const uint32_t segs = (len + 7u) >> 3;
+        const uint32_t incl = wave_incl_scan(segs), excl = incl - segs;
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (k < segs) s_seg[excl + k] = (uint8_t)lane;
+        wave_lds_sync();
+        const int nstep = (int)((total + 7u) >> 3);
+        uint32_t rcA[GATHER_U], rcB[GATHER_U];
+        uint64_t slA[NEED_SL ? GATHER_U : 1], slB[NEED_SL ? GATHER_U : 1];
+        bool okA[GATHER_U], okB[GATHER_U];
+        auto issue = [&](int t, uint32_t (&rc)[GATHER_U], uint64_t (&sl)[NEED_SL ? GATHER_U : 1], bool (&ok)[GATHER_U]) {
+#pragma unroll
+            for (int u = 0; u < GATHER_U; ++u) {
+                const uint32_t q = (uint32_t)(t + u) * 8u + g;
+                const bool has = q < total;
+                const int r = has ? (int)s_seg[q] : 0;
+                const uint64_t dd = (uint64_t)__shfl((unsigned long long)d, r, 64);
+                const uint32_t ex = (uint32_t)__shfl((int)excl, r, 64);
+                const uint32_t off = (q - ex) * 8u + gl;
+                const uint64_t slot = (dd >> 8) + off;
+                if (NEED_SL) sl[NEED_SL ? u : 0] = slot;
+                ok[u] = has && off < (uint32_t)(dd & 0xFFull);
+                rc[u] = ok[u] ? rec[slot] : 0u;
+            }
+        };
+        if (nstep > 0) issue(0, rcA, slA, okA);
+        for (int t = 0; t < nstep; t += 2 * GATHER_U) {
+            const bool hasB = t + GATHER_U < nstep;
+            if (hasB) issue(t + GATHER_U, rcB, slB, okB);
+            fb(rcA, slA, okA);
+            if (t + 2 * GATHER_U < nstep) issue(t + 2 * GATHER_U, rcA, slA, okA);
+            if (hasB) fb(rcB, slB, okB);
+        }
+        wave_lds_sync();                                                   // s_seg is rewritten by the next chunk
+        d = dn;
+    }
+}
+
 template <int NW, int GATHER_U, typename F>
 __device__ __forceinline__ void for_each_record(const uint64_t* sorted_desc, const uint32_t* rec, uint64_t r0, uint64_t r1,
                                                 int wid, F f) {
@@ -1290,7 +1350,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     // Multi-wave bins keep a dense list of the occupied slots, appended to when a key enters the table: the top-k passes
     // walk ceil(occupied / THREADS) entries per lane instead of T / THREADS slots (the tables run 15 - 40 % full), and the
     // table is cleared through the list. More distinct keys than OCAP: the passes fall back to walking the table.
-    constexpr int OCAP = NW == 1 ? 1 : (LOG2T == 12 ? 2048 : (LOG2T == 14 ? 12288 : (THREADS == 512 ? 5632 : 6144)));
+    constexpr int OCAP = NW == 1 ? 1 : (LOG2T == 12 ? 1920 : (LOG2T == 14 ? 10240 : (THREADS == 512 ? 4608 : 6144)));
     constexpr int RCAP = OCAP / NW;         // one list region per wave: appended to with a wave-private counter (no atomics)
     __shared__ uint16_t s_occ[OCAP];
     __shared__ uint32_t s_wcnt[NW];         // keys each wave entered into the table (published after the insert phase)
@@ -1305,6 +1365,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     __shared__ uint32_t s_ovf;
     constexpr int LISTCAP = BOUND ? S_CAP : 256;
     __shared__ uint16_t s_list[NW == 1 ? LISTCAP : 1];                         // one-wave bins: compacted valid slots
+    __shared__ uint8_t s_seg[NW][256];                                         // gather: segment -> descriptor lane, per wave
     __shared__ ItemDesc s_cur;
     __shared__ ItemDesc s_nxt;                                                // the item after s_cur (for the record prefetch)
 
@@ -1658,14 +1719,15 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 if (s_ovf) break;
             }
         } else {
-            for_each_record_batch<NW, GU>(a.sorted_desc, a.rec, cur.rb, cur.re, wid,
-                                          [&](uint32_t (&rc)[GU], uint64_t (&sl)[GU], bool (&ok)[GU]) {
+            constexpr bool NEED_SL = GROUP == OTTO_COVIS_GROUP_TIME;
+            for_each_record_seg<NW, GU, NEED_SL>(a.sorted_desc, a.rec, cur.rb, cur.re, wid, s_seg[wid],
+                                                 [&](uint32_t (&rc)[GU], uint64_t (&sl)[NEED_SL ? GU : 1], bool (&ok)[GU]) {
                 uint32_t e[GU];
                 bool okb[GU];
 #pragma unroll
                 for (int u = 0; u < GU; ++u) {
                     okb[u] = ok[u] && (lgR == 0 || ((rec_hash(rc[u]) >> pshift) & pmask) == part);
-                    e[u] = (GROUP == OTTO_COVIS_GROUP_TIME && okb[u]) ? a.tw[sl[u]] : 0u;
+                    e[u] = (GROUP == OTTO_COVIS_GROUP_TIME && okb[u]) ? a.tw[sl[NEED_SL ? u : 0]] : 0u;
                 }
                 insert_batch(std::integral_constant<int, GU>{}, rc, okb, e);
             });
