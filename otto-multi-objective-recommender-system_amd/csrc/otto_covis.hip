@@ -2225,11 +2225,25 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                             if (kbetter(o, gb)) gb = o;
                         }
                     }
-                    wave_bitonic_sort_desc(gb);
-                    const K thr = kshfl(gb, a.k - 1);
+                    // k-th best of the 64 group bests by counting (rank = number of better keys, read back with uniform
+                    // addresses: 64 independent iterations instead of the 21 dependent stages of a sorting network)
+                    kstore(gb, &s_exw[wid][lane], &s_exy[0][WIDE ? lane : 0]);
+                    wave_lds_sync();
+                    uint32_t rank = 0;
+#pragma unroll 8
+                    for (int i = 0; i < 64; ++i) {
+                        K o;
+                        kload(o, s_exw[wid][i], s_exy[0][WIDE ? i : 0]);
+                        rank += kbetter(o, gb) ? 1u : 0u;
+                    }
+                    const uint64_t mk = __ballot(kvalid(gb) && rank == (uint32_t)(a.k - 1));
+                    K thr;
+                    kclear(thr);
+                    if (mk) thr = kshfl(gb, __ffsll((unsigned long long)mk) - 1);
                     if (lane == 0) kstore(thr, &s_thrw[wid], &s_thry[wid]);
-                    // lane 31: a lower bound of the partition's 32nd best key = the guess for the aid's other partitions
-                    if (use_guess && lane == 31u && kvalid(gb)) ktau_store(gb, a.tau_w, a.tau_y, (size_t)wid * a.n_aids + x);
+                    // rank 31: a lower bound of the partition's 32nd best key = the guess for the aid's other partitions
+                    if (use_guess && kvalid(gb) && rank == 31u) ktau_store(gb, a.tau_w, a.tau_y, (size_t)wid * a.n_aids + x);
+                    wave_lds_sync();
                 }
                 OTTO_PH(5);
                 __syncthreads();
@@ -2969,14 +2983,14 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
         uint32_t grid = a.n_items < 256u * 20u ? a.n_items : 256u * 20u;
         tbegin(c, OTTO_COVIS_T_REDUCE_S, s);
         prof_begin();
-        OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_S, grid, S_THREADS, a, S_LOG2T, S_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, 5, 8);
+        OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_S, grid, S_THREADS, a, S_LOG2T, S_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, 5, 4);
         prof_end("S", a.n_work);
         tend(c, OTTO_COVIS_T_REDUCE_S, s);
     } else if (bin == 1) {
         uint32_t grid = a.n_items < 256u * 4u ? a.n_items : 256u * 4u;
         tbegin(c, OTTO_COVIS_T_REDUCE_M, s);
         prof_begin();
-        OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_M, grid, M_THREADS, a, M_LOG2T, M_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, (GROUP != OTTO_COVIS_GROUP_TIME ? 4 : 2), 8);
+        OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_M, grid, M_THREADS, a, M_LOG2T, M_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, (GROUP != OTTO_COVIS_GROUP_TIME ? 4 : 2), 4);
         prof_end("M", a.n_work);
         tend(c, OTTO_COVIS_T_REDUCE_M, s);
     } else {
