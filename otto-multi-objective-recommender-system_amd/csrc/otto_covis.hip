@@ -1857,7 +1857,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 wave_lds_sync();
                 uint32_t ncand = 0;
                 bool overflow = nvalid > (uint32_t)LISTCAP;          // cannot happen (an S aid has <= S_CAP records); exact fallback anyway
-                if (nvalid <= 32u || nvalid <= (uint32_t)a.k) {
+                if (nvalid <= 40u || nvalid <= (uint32_t)a.k) {
                     // every occupied slot is a candidate
                     if (lane < nvalid) s_cand[lane] = s_list[NW == 1 ? lane : 0];
                     ncand = nvalid;
@@ -1871,8 +1871,17 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                         slot_lohi((int)s_list[NW == 1 ? li : 0], kl, kh);
                         if (kbetter(kl, lb)) lb = kl;
                     }
-                    wave_bitonic_sort_desc(lb);
-                    const K thr = kshfl(lb, a.k - 1);
+                    // k-th best lane-best by counting (64 independent LDS broadcasts instead of a 21-stage network)
+                    s_exw[0][lane] = lb.c;
+                    wave_lds_sync();
+                    uint32_t rk = 0;
+#pragma unroll 8
+                    for (int i = 0; i < 64; ++i) rk += s_exw[0][i] > lb.c ? 1u : 0u;
+                    const uint64_t mk = __ballot(kvalid(lb) && rk == (uint32_t)(a.k - 1));
+                    K thr;
+                    kclear(thr);
+                    if (mk) thr = kshfl(lb, __ffsll((unsigned long long)mk) - 1);
+                    wave_lds_sync();
                     for (uint32_t l0 = 0; l0 < nvalid; l0 += 64u) {
                         const uint32_t li = l0 + lane;
                         bool c = false;
