@@ -2206,7 +2206,23 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 int bi[PKD];
 #pragma unroll
                 for (int j = 0; j < PKD; ++j) { kclear(lb[j]); bi[j] = 0xFFFF; }
-                for (int q = 0; q < nit; ++q) {
+                // the keys of the lane's first NCK entries stay in registers for P3 (the dense list gives a lane 2 - 4 entries
+                // in the common case: P3 then recomputes nothing)
+                constexpr int NCK = (PACKED && THREADS <= 512) ? 3 : 0;
+                K ck[NCK > 0 ? NCK : 1][PKD];
+#pragma unroll
+                for (int q = 0; q < NCK; ++q) {
+                    const int sl = q < nit ? slot_at(q) : -1;
+#pragma unroll
+                    for (int j = 0; j < PKD; ++j) kclear(ck[q][j]);
+                    if (sl >= 0) {
+                        slot_keys(sl, ck[q]);
+#pragma unroll
+                        for (int j = 0; j < PKD; ++j)
+                            if (kbetter(ck[q][j], lb[j])) { lb[j] = ck[q][j]; bi[j] = sl; }
+                    }
+                }
+                for (int q = NCK; q < nit; ++q) {
                     const int sl = slot_at(q);
                     if (sl < 0) continue;
                     K kk[PKD];
@@ -2259,7 +2275,13 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 K thr[PKD];
 #pragma unroll
                 for (int j = 0; j < PKD; ++j) kload(thr[j], s_thrw[j], s_thry[j]);
-                for (int q = 0; q < nit; ++q) {
+#pragma unroll
+                for (int q = 0; q < NCK; ++q) {
+#pragma unroll
+                    for (int j = 0; j < PKD; ++j)
+                        if (j < a.nk && kvalid(ck[q][j]) && !kbetter(thr[j], ck[q][j])) append(j, ck[q][j]);
+                }
+                for (int q = NCK; q < nit; ++q) {
                     const int sl = slot_at(q);
                     if (sl < 0) continue;
                     K kk[PKD];
