@@ -1180,8 +1180,8 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
     __shared__ uint32_t s_delta[SCATTER ? RL : 1];     // (global bucket position - position in the stage) per partition
     __shared__ uint32_t s_stage[SCATTER ? PART_STAGE : 1];
     __shared__ uint32_t s_stage_tw[(SCATTER && TW) ? PART_STAGE : 1];
-    __shared__ uint32_t s_scan[256 / 64 + 1];
     __shared__ uint32_t s_full;                        // a capacity-sized bucket of this chunk's aid is full
+    __shared__ uint32_t s_n;                           // records staged so far
     const int wid = threadIdx.x >> 6;
     for (uint32_t ci = blockIdx.x; ci < a.n_chunks; ci += gridDim.x) {
         const uint64_t ch = a.chunks[ci];
@@ -1215,62 +1215,63 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
             continue;
         }
         for (uint32_t p = threadIdx.x; p < R; p += 256) s_cnt[p] = 0;
-        if (threadIdx.x == 0) s_full = 0;
-        __syncthreads();
-        for_each_record<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t) {
-            atomicAdd(&s_cnt[(rec_hash(rc) >> pshift) & pmask], 1u);
-        });
+        if (threadIdx.x == 0) { s_full = 0; s_n = 0; }
         __syncthreads();
         if (!SCATTER) {
+            for_each_record<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t) {
+                atomicAdd(&s_cnt[(rec_hash(rc) >> pshift) & pmask], 1u);
+            });
+            __syncthreads();
             for (uint32_t p = threadIdx.x; p < R; p += 256) {
                 const uint32_t n = s_cnt[p];
                 if (n) atomicAdd(&a.pcount[g0 + p], n);
             }
         } else {
-            // exclusive scan of the chunk's per-partition counts -> positions in the LDS stage; one global
-            // cursor bump per (chunk, partition) reserves the matching bucket range
-            constexpr int PPT = RL / 256;                  // partitions per thread
-            uint32_t cnt[PPT], tsum = 0;
+            // ONE pass over the chunk's records: they land in the LDS stage in arrival order (wave-aggregated cursor)
+            // while the per-partition histogram is taken; the scatter then reads them back from LDS
+            const unsigned lane = lane_id();
+            for_each_record_batch<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t (&rc)[8], uint64_t (&sl)[8], bool (&ok)[8]) {
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) {
-                const uint32_t p = threadIdx.x * PPT + q;
-                cnt[q] = p < R ? s_cnt[p] : 0u;
-                tsum += cnt[q];
-            }
-            uint32_t total;
-            uint32_t off = block_excl_scan<uint32_t, 256>(tsum, s_scan, &total);
-#pragma unroll
-            for (int q = 0; q < PPT; ++q) {
-                const uint32_t p = threadIdx.x * PPT + q;
-                if (p < R) {
-                    uint32_t gpos = 0;
-                    if (cnt[q]) {
-                        const uint32_t old = atomicAdd(&a.pcursor[g0 + p], cnt[q]);
-                        gpos = (uint32_t)(a.pstart[g0 + p] - x_base) + old;
-                        if ((uint64_t)old + cnt[q] > a.pstart[g0 + p + 1] - a.pstart[g0 + p]) s_full = 1u;   // full: nothing of this chunk is written
+                for (int u = 0; u < 8; ++u) {
+                    const uint64_t m = __ballot(ok[u]);
+                    if (m == 0) continue;
+                    const int leader = __ffsll((unsigned long long)m) - 1;
+                    uint32_t base = 0;
+                    if ((int)lane == leader) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
+                    base = (uint32_t)__shfl((int)base, leader, 64);
+                    if (ok[u]) {
+                        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        s_stage[SCATTER ? pos : 0] = rc[u];
+                        if (TW) s_stage_tw[(SCATTER && TW) ? pos : 0] = a.tw[sl[u]];
+                        atomicAdd(&s_cnt[(rec_hash(rc[u]) >> pshift) & pmask], 1u);
                     }
-                    s_delta[p] = gpos - off;
-                    s_cnt[p] = off;
-                    off += cnt[q];
                 }
-            }
-            __syncthreads();
-            for_each_record<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t slot) {
-                const uint32_t p = (rec_hash(rc) >> pshift) & pmask;
-                const uint32_t pos = atomicAdd(&s_cnt[p], 1u);
-                s_stage[pos] = rc;
-                if (TW) s_stage_tw[(SCATTER && TW) ? pos : 0] = a.tw[slot];
             });
             __syncthreads();
-            if (s_full) {                                              // block-uniform (written before two barriers)
+            const uint32_t total = s_n;
+            // one global cursor bump per (chunk, partition) reserves the chunk's piece of every bucket
+            for (uint32_t p = threadIdx.x; p < R; p += 256) {
+                const uint32_t n = s_cnt[p];
+                uint32_t gpos = 0;
+                if (n) {
+                    const uint32_t old = atomicAdd(&a.pcursor[g0 + p], n);
+                    gpos = (uint32_t)(a.pstart[g0 + p] - x_base) + old;
+                    if ((uint64_t)old + n > a.pstart[g0 + p + 1] - a.pstart[g0 + p]) s_full = 1u;   // full: nothing of this chunk is written
+                }
+                s_delta[SCATTER ? p : 0] = gpos;
+                s_cnt[p] = 0;
+            }
+            __syncthreads();
+            if (s_full) {                                              // block-uniform
                 if (threadIdx.x == 0 && atomicExch(&a.flag[x], 1u) == 0u) atomicAdd(a.ovf_count, 1u);
                 __syncthreads();
                 continue;
             }
-            // the stage is grouped by partition: consecutive threads write consecutive bucket addresses
+            // a partition's records of this chunk go to one contiguous piece of its bucket (order inside is free)
             for (uint32_t i = threadIdx.x; i < total; i += 256) {
-                const uint32_t rc = s_stage[i];
-                const uint64_t o = x_base + (uint32_t)(s_delta[(rec_hash(rc) >> pshift) & pmask] + i);
+                const uint32_t rc = s_stage[SCATTER ? i : 0];
+                const uint32_t p = (rec_hash(rc) >> pshift) & pmask;
+                const uint64_t o = x_base + (uint64_t)(s_delta[SCATTER ? p : 0] + atomicAdd(&s_cnt[p], 1u));
                 a.prec[o] = rc;
                 if (TW) a.ptw[o] = s_stage_tw[(SCATTER && TW) ? i : 0];
             }

@@ -36,4 +36,17 @@ eng = MFEngine(OTTO_N_SESSIONS, OTTO_N_AIDS, 64, rows, device=dev)
 for e in range(2):
     eng.bpr_step(U, V, u, i, 42, e, 0, 0.05, 0.0, BPR_HOGWILD)
 torch.cuda.synchronize()
+del U, V, eng
+# reference-config R-MF steps (MSELoss + SparseAdam, 32 factors, batch 262,144)
+B, dr = 262144, 32
+E1 = torch.randn(OTTO_N_SESSIONS, dr, device=dev)
+E2 = torch.randn(OTTO_N_AIDS + 1, dr, device=dev)
+st = [torch.zeros_like(E1), torch.zeros_like(E1), torch.zeros_like(E2), torch.zeros_like(E2)]
+er = MFEngine(OTTO_N_SESSIONS, OTTO_N_AIDS + 1, dr, B, device=dev)
+tg = torch.randint(0, 3, (rows,), device=dev)
+lo_ = torch.zeros(1, device=dev)
+for b in range(4):
+    sl = slice(b * B, (b + 1) * B)
+    er.step_sparse_adam(E1, st[0], st[1], E2, st[2], st[3], u[sl], i[sl], tg[sl], 0, 0.05, (0.9, 0.999), 1e-8, b + 1, lo_)
+torch.cuda.synchronize()
 print('done')
