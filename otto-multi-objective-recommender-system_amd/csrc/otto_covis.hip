@@ -1182,6 +1182,7 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
     __shared__ uint32_t s_stage_tw[(SCATTER && TW) ? PART_STAGE : 1];
     __shared__ uint32_t s_full;                        // a capacity-sized bucket of this chunk's aid is full
     __shared__ uint32_t s_n;                           // records staged so far
+    __shared__ uint8_t s_seg[NW][256];                 // gather: segment -> descriptor lane, per wave
     const int wid = threadIdx.x >> 6;
     for (uint32_t ci = blockIdx.x; ci < a.n_chunks; ci += gridDim.x) {
         const uint64_t ch = a.chunks[ci];
@@ -1230,9 +1231,9 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
             // ONE pass over the chunk's records: they land in the LDS stage in arrival order (wave-aggregated cursor)
             // while the per-partition histogram is taken; the scatter then reads them back from LDS
             const unsigned lane = lane_id();
-            for_each_record_batch<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t (&rc)[8], uint64_t (&sl)[8], bool (&ok)[8]) {
+            for_each_record_seg<NW, 4, TW>(a.sorted_desc, a.rec, rb, re, wid, s_seg[wid], [&](uint32_t (&rc)[4], uint64_t (&sl)[TW ? 4 : 1], bool (&ok)[4]) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 4; ++u) {
                     const uint64_t m = __ballot(ok[u]);
                     if (m == 0) continue;
                     const int leader = __ffsll((unsigned long long)m) - 1;
@@ -1242,7 +1243,7 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
                     if (ok[u]) {
                         const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                         s_stage[SCATTER ? pos : 0] = rc[u];
-                        if (TW) s_stage_tw[(SCATTER && TW) ? pos : 0] = a.tw[sl[u]];
+                        if (TW) s_stage_tw[(SCATTER && TW) ? pos : 0] = a.tw[sl[TW ? u : 0]];
                         atomicAdd(&s_cnt[(rec_hash(rc[u]) >> pshift) & pmask], 1u);
                     }
                 }
