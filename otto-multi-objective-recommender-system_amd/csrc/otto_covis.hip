@@ -1310,6 +1310,46 @@ __global__ void k_fill_chunks(ChunkCount f, uint32_t n_aids, const uint64_t* chu
     for (uint64_t q = 0; q < c; ++q) chunks[s + q] = (uint64_t)x | (q << 26);
 }
 
+// Every total the index build needs on the host (buffer sizes, statistics) in ONE reduction over the aids, so the build
+// synchronises with the host once instead of after each of its scans:
+//   [0] records  [1] runs  [2..4] records per bin  [5..7] runs per bin  [8..10] work items per bin
+//   [11..13] heavy items per layout  [14..16] heavy aids per layout (pilots)  [17] partition chunks
+constexpr int N_TOTALS = 18;
+__global__ __launch_bounds__(256) void k_aid_totals(const uint64_t* cnt64, const uint8_t* boost, const uint32_t* flag, uint32_t n_aids,
+                                                    uint32_t l_cap, int allow_packed, unsigned long long* totals) {
+    __shared__ unsigned long long s_t[4][N_TOTALS];
+    unsigned long long t[N_TOTALS];
+#pragma unroll
+    for (int q = 0; q < N_TOTALS; ++q) t[q] = 0;
+    for (uint32_t x = blockIdx.x * 256 + threadIdx.x; x < n_aids; x += gridDim.x * 256) {
+        const uint64_t c64 = cnt64[x], n = c64 & CNT_REC_MASK, r = c64 >> CNT_REC_BITS;
+        if (n == 0) continue;
+        const int b = n <= (uint64_t)S_CAP ? 0 : (n <= (uint64_t)M_CAP ? 1 : 2);
+        t[0] += n; t[1] += r; t[2 + b] += n; t[5 + b] += r;
+        ItemCount f{cnt64, boost, flag, b, 0, l_cap, allow_packed, -1};
+        const uint64_t items = f((int64_t)x);
+        t[8 + b] += items;
+        if (b == 2) {
+            const int mode = heavy_mode(c64, allow_packed, l_cap);
+            t[11 + mode] += items;
+            t[14 + mode] += 1;
+            ChunkCount cf{cnt64, boost, flag, 0, l_cap, allow_packed};
+            t[17] += cf((int64_t)x);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < N_TOTALS; ++q) {
+        unsigned long long v = t[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane_id() == 0) s_t[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < N_TOTALS) {
+        const unsigned long long v = s_t[0][threadIdx.x] + s_t[1][threadIdx.x] + s_t[2][threadIdx.x] + s_t[3][threadIdx.x];
+        if (v) atomicAdd(&totals[threadIdx.x], v);
+    }
+}
+
 // ---- the reduce kernel --------------------------------------------------------------------------------
 // PACKED (S / M bins, not the time group): a table slot is ONE 64-bit word  aid_y << 36 | c2 << 24 | c1 << 12 | c0
 // (an aid of these bins has <= M_CAP < 4096 records, so no 12-bit counter can overflow): one LDS read per probe,
@@ -2818,14 +2858,17 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
     return 0;
 }
 
-static int build_items(otto_covis_ctx* c, int bin, int only_flagged, hipStream_t s, int allow_packed = 0) {
+// pre (nullable): the totals of k_aid_totals for this configuration -- no host synchronisation then
+static int build_items(otto_covis_ctx* c, int bin, int only_flagged, hipStream_t s, int allow_packed = 0, const uint64_t* pre = nullptr) {
     const uint32_t n_aids = c->p.n_aids;
     ItemCount f{c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(), c->flag.as<uint32_t>(), bin, only_flagged, c->l_cap, allow_packed, -1};
     if (bin == 2) c->items_allow_packed = allow_packed;
     OTTO_TRY(device_scan(f, (int64_t)n_aids, c->item_start.as<uint64_t>(), c->partial.as<uint64_t>(), s));
-    uint64_t total = 0;
-    OTTO_HIP(hipMemcpyAsync(&total, c->item_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
-    OTTO_HIP(hipStreamSynchronize(s));
+    uint64_t total = pre ? pre[8 + bin] : 0;
+    if (!pre) {
+        OTTO_HIP(hipMemcpyAsync(&total, c->item_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
+        OTTO_HIP(hipStreamSynchronize(s));
+    }
     OTTO_REQUIRE(total < (1ull << 32), "too many work items (%llu)", (unsigned long long)total);
     c->n_items[bin] = total;
     if (total) {
@@ -2844,10 +2887,12 @@ static int build_items(otto_covis_ctx* c, int bin, int only_flagged, hipStream_t
             OTTO_TRY(c->lmode_start.ensure((size_t)(n_aids + 1) * 8, 0, s));
             OTTO_TRY(device_scan(ItemAny{fm}, (int64_t)n_aids, c->lrank.as<uint64_t>(), c->partial.as<uint64_t>(), s));
             OTTO_TRY(device_scan(fm, (int64_t)n_aids, c->lmode_start.as<uint64_t>(), c->partial.as<uint64_t>(), s));
-            uint64_t n_pilots = 0, n_mode = 0;
-            OTTO_HIP(hipMemcpyAsync(&n_pilots, c->lrank.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
-            OTTO_HIP(hipMemcpyAsync(&n_mode, c->lmode_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
-            OTTO_HIP(hipStreamSynchronize(s));
+            uint64_t n_pilots = pre ? pre[14 + mode] : 0, n_mode = pre ? pre[11 + mode] : 0;
+            if (!pre) {
+                OTTO_HIP(hipMemcpyAsync(&n_pilots, c->lrank.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
+                OTTO_HIP(hipMemcpyAsync(&n_mode, c->lmode_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
+                OTTO_HIP(hipStreamSynchronize(s));
+            }
             c->n_order[bin][mode] = n_mode;
             if (!n_mode) continue;
             OTTO_TRY(c->lorder[bin][mode].ensure((size_t)n_mode * 4, 0, s));
@@ -2862,9 +2907,11 @@ static int build_items(otto_covis_ctx* c, int bin, int only_flagged, hipStream_t
         OTTO_HIP(hipMemcpyAsync(c->litem_start.p, c->item_start.p, (size_t)(n_aids + 1) * 8, hipMemcpyDeviceToDevice, s));
         ChunkCount cf{c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(), c->flag.as<uint32_t>(), only_flagged, c->l_cap, allow_packed};
         OTTO_TRY(device_scan(cf, (int64_t)n_aids, c->item_start.as<uint64_t>(), c->partial.as<uint64_t>(), s));
-        uint64_t nch = 0;
-        OTTO_HIP(hipMemcpyAsync(&nch, c->item_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
-        OTTO_HIP(hipStreamSynchronize(s));
+        uint64_t nch = pre ? pre[17] : 0;
+        if (!pre) {
+            OTTO_HIP(hipMemcpyAsync(&nch, c->item_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
+            OTTO_HIP(hipStreamSynchronize(s));
+        }
         OTTO_REQUIRE(nch < (1ull << 32), "too many partition chunks");
         c->n_chunks = nch;
         if (nch) {
@@ -2885,7 +2932,7 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
     OTTO_TRY(c->run_rank.ensure((size_t)(c->run_used ? c->run_used : 1) * 4, 0, s));
     OTTO_TRY(c->boost.ensure((size_t)n_aids, 0, s));
     OTTO_TRY(c->flag.ensure((size_t)n_aids * 4, 0, s));
-    OTTO_TRY(c->counters.ensure(64, 0, s));
+    OTTO_TRY(c->counters.ensure(512, 0, s));
     OTTO_TRY(c->partial.ensure(scan_partial_bytes((int64_t)n_aids), 0, s));
     OTTO_HIP(hipMemsetAsync(c->cnt64.p, 0, (size_t)n_aids * 8, s));
     OTTO_HIP(hipMemsetAsync(c->boost.p, 0, (size_t)n_aids, s));
@@ -2931,15 +2978,21 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
                                          c->run_rank.as<uint32_t>(), n_aids);
         OTTO_HIP(hipGetLastError());
     }
-    // total pairs (records) and runs
-    OTTO_TRY(device_scan(RecCount{c->cnt64.as<uint64_t>()}, (int64_t)n_aids, c->run_start.as<uint64_t>(), c->partial.as<uint64_t>(), s));
-    uint64_t tot[2] = {0, 0};
-    OTTO_HIP(hipMemcpyAsync(&tot[0], c->run_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
+    // every total the build needs on the host in one reduction + ONE synchronisation (boost / flag are zero here)
+    uint64_t tot[N_TOTALS];
+    {
+        unsigned long long* d_tot = c->counters.as<unsigned long long>() + 4;        // counters: 64 u64 words, [4, 4 + N_TOTALS) here
+        OTTO_HIP(hipMemsetAsync(d_tot, 0, N_TOTALS * 8, s));
+        k_aid_totals<<<256 * 4, 256, 0, s>>>(c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(), c->flag.as<uint32_t>(), n_aids, c->l_cap,
+                                             c->packed_heavy, d_tot);
+        OTTO_HIP(hipGetLastError());
+        OTTO_HIP(hipMemcpyAsync(tot, d_tot, N_TOTALS * 8, hipMemcpyDeviceToHost, s));
+    }
     OTTO_TRY(device_scan(RunCount{c->cnt64.as<uint64_t>()}, (int64_t)n_aids, c->run_start.as<uint64_t>(), c->partial.as<uint64_t>(), s));
-    OTTO_HIP(hipMemcpyAsync(&tot[1], c->run_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
     OTTO_HIP(hipStreamSynchronize(s));
     c->n_pairs = tot[0];
     c->n_runs = tot[1];
+    for (int bin = 0; bin < 3; ++bin) { c->bin_pairs[bin] = tot[2 + bin]; c->bin_runs[bin] = tot[5 + bin]; }
     OTTO_TRY(c->sorted_desc.ensure((size_t)(c->n_runs ? c->n_runs : 1) * 8, 0, s));
     if (bucketed) {
         ba.run_start = c->run_start.as<uint64_t>();
@@ -2953,15 +3006,7 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
                                             n_slots, c->run_start.as<uint64_t>(), c->sorted_desc.as<uint64_t>(), n_aids);
         OTTO_HIP(hipGetLastError());
     }
-    for (int bin = 0; bin < 3; ++bin) {
-        OTTO_TRY(device_scan(BinRecs{c->cnt64.as<uint64_t>(), bin}, (int64_t)n_aids, c->item_start.as<uint64_t>(),
-                             c->partial.as<uint64_t>(), s));
-        OTTO_HIP(hipMemcpyAsync(&c->bin_pairs[bin], c->item_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
-        OTTO_TRY(device_scan(BinRuns{c->cnt64.as<uint64_t>(), bin}, (int64_t)n_aids, c->item_start.as<uint64_t>(),
-                             c->partial.as<uint64_t>(), s));
-        OTTO_HIP(hipMemcpyAsync(&c->bin_runs[bin], c->item_start.as<uint64_t>() + n_aids, 8, hipMemcpyDeviceToHost, s));
-        OTTO_TRY(build_items(c, bin, 0, s, c->packed_heavy));
-    }
+    for (int bin = 0; bin < 3; ++bin) OTTO_TRY(build_items(c, bin, 0, s, c->packed_heavy, tot));
     tend(c, OTTO_COVIS_T_INDEX, s);
     c->retries = 0;
     c->index_valid = true;
