@@ -699,22 +699,18 @@ __global__ __launch_bounds__(BKT_THREADS) void k_bkt_split(BktArgs a) {
     }
 }
 
-// one workgroup per bucket. PLACE = false: cnt64 of the bucket's aids; PLACE = true: sorted_desc.
-template <bool PLACE>
-__global__ __launch_bounds__(BKT_THREADS) void k_bkt_local(BktArgs a) {
-    extern __shared__ unsigned long long s_dyn[];          // [1 << sh]: runs << 36 | records, or start positions
-    uint32_t* s_cur = reinterpret_cast<uint32_t*>(s_dyn + ((size_t)1 << a.sh));   // PLACE: [1 << sh] cursors
+// count + scan + place of one bucket in ONE workgroup (replaces k_bkt_local<false>, the device-wide scan of the run counts
+// and k_bkt_local<true>): the first run of aid x is the bucket's first run (bstart[b], known from the split) + the runs of
+// the bucket's aids before x, so the prefix is a block scan in LDS; the second walk over the bucket's runs hits L2.
+__global__ __launch_bounds__(BKT_THREADS) void k_bkt_fused(BktArgs a, uint64_t* run_start_out) {
+    extern __shared__ unsigned long long s_dyn[];          // [1 << sh]: runs << 36 | records, then start positions
+    uint32_t* s_cur = reinterpret_cast<uint32_t*>(s_dyn + ((size_t)1 << a.sh));   // [1 << sh] cursors
+    __shared__ uint32_t s_sc[BKT_THREADS / 64 + 1];
     const uint32_t ab = 1u << a.sh;
+    const uint32_t per = ab / BKT_THREADS > 0 ? ab / BKT_THREADS : 1u;
     for (uint32_t b = blockIdx.x; b < a.nb; b += gridDim.x) {
         const uint32_t x0 = b << a.sh;
-        for (uint32_t i = threadIdx.x; i < ab; i += BKT_THREADS) {
-            if (PLACE) {
-                s_dyn[i] = x0 + i < a.n_aids ? a.run_start[x0 + i] : 0ull;
-                s_cur[i] = 0;
-            } else {
-                s_dyn[i] = 0;
-            }
-        }
+        for (uint32_t i = threadIdx.x; i < ab; i += BKT_THREADS) { s_dyn[i] = 0; s_cur[i] = 0; }
         __syncthreads();
         const uint64_t e0 = a.bstart[b], e1 = a.bstart[b + 1];
         for (uint64_t i0 = e0 + threadIdx.x; i0 < e1; i0 += 4 * BKT_THREADS) {
@@ -729,16 +725,48 @@ __global__ __launch_bounds__(BKT_THREADS) void k_bkt_local(BktArgs a) {
                 xl[u] = (uint32_t)r.y - x0;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!d[u]) continue;
-                if (PLACE) a.sorted_desc[s_dyn[xl[u]] + atomicAdd(&s_cur[xl[u]], 1u)] = d[u];
-                else atomicAdd(&s_dyn[xl[u]], (1ull << CNT_REC_BITS) | (d[u] & 0xFFull));
-            }
+            for (int u = 0; u < 4; ++u)
+                if (d[u]) atomicAdd(&s_dyn[xl[u]], (1ull << CNT_REC_BITS) | (d[u] & 0xFFull));
         }
         __syncthreads();
-        if (!PLACE)
-            for (uint32_t i = threadIdx.x; i < ab; i += BKT_THREADS)
-                if (x0 + i < a.n_aids) a.cnt64[x0 + i] = s_dyn[i];
+        // counts out, exclusive scan of the run counts over the bucket's aids (thread t: aids t * per .. + per)
+        uint32_t mine = 0;
+        for (uint32_t q = 0; q < per; ++q) {
+            const uint32_t i = threadIdx.x * per + q;
+            if (i < ab) {
+                const unsigned long long c64 = s_dyn[i];
+                if (x0 + i < a.n_aids) a.cnt64[x0 + i] = c64;
+                mine += (uint32_t)(c64 >> CNT_REC_BITS);
+            }
+        }
+        uint32_t tot;
+        uint32_t run = block_excl_scan<uint32_t, BKT_THREADS>(mine, s_sc, &tot);
+        for (uint32_t q = 0; q < per; ++q) {
+            const uint32_t i = threadIdx.x * per + q;
+            if (i < ab) {
+                const uint32_t n = (uint32_t)(s_dyn[i] >> CNT_REC_BITS);
+                s_dyn[i] = e0 + run;
+                if (x0 + i < a.n_aids) run_start_out[x0 + i] = e0 + run;
+                run += n;
+            }
+        }
+        if (b == a.nb - 1 && threadIdx.x == 0) run_start_out[a.n_aids] = e1;
+        __syncthreads();
+        for (uint64_t i0 = e0 + threadIdx.x; i0 < e1; i0 += 4 * BKT_THREADS) {
+            uint32_t xl[4];
+            uint64_t d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint64_t i = i0 + (uint64_t)u * BKT_THREADS;
+                ulonglong2 r = make_ulonglong2(0ull, 0ull);
+                if (i < e1) r = a.tmp[i];
+                d[u] = r.x;
+                xl[u] = (uint32_t)r.y - x0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (d[u]) a.sorted_desc[s_dyn[xl[u]] + atomicAdd(&s_cur[xl[u]], 1u)] = d[u];
+        }
         __syncthreads();
     }
 }
@@ -2954,7 +2982,7 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
         ba.bcount = c->bcount.as<uint32_t>();
         const int64_t n_chunks = (n_slots + BKT_CHUNK - 1) / BKT_CHUNK;
         const int sgrid = (int)(n_chunks < 256 * 2 ? n_chunks : 256 * 2);
-        kname(c, OTTO_COVIS_T_INDEX, "k_bkt_split<false/true> + k_bkt_local<false/true> + k_scan_* + k_fill_*");
+        kname(c, OTTO_COVIS_T_INDEX, "k_bkt_split<false/true> + k_bkt_fused + k_aid_totals + k_scan_* + k_fill_*");
         k_bkt_split<false><<<sgrid, BKT_THREADS, 0, s>>>(ba);
         OTTO_HIP(hipGetLastError());
         OTTO_TRY(device_scan(BktCount{ba.bcount}, (int64_t)ba.nb, c->bstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
@@ -2969,7 +2997,11 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
         OTTO_HIP(hipGetLastError());
         ba.cnt64 = c->cnt64.as<uint64_t>();
         const int lgrid = (int)(ba.nb < 256u * 2u ? ba.nb : 256u * 2u);
-        k_bkt_local<false><<<lgrid, BKT_THREADS, (size_t)8 << ba.sh, s>>>(ba);
+        // the split left every bucket's runs contiguous: the total is known, counting / scanning / placing is one launch
+        c->n_runs = n_runs_b;
+        OTTO_TRY(c->sorted_desc.ensure((size_t)(c->n_runs ? c->n_runs : 1) * 8, 0, s));
+        ba.sorted_desc = c->sorted_desc.as<uint64_t>();
+        k_bkt_fused<<<lgrid, BKT_THREADS, (size_t)12 << ba.sh, s>>>(ba, c->run_start.as<uint64_t>());
         OTTO_HIP(hipGetLastError());
     } else if (n_slots) {
         int grid = (int)((n_slots + 255) / 256 < 256 * 32 ? (n_slots + 255) / 256 : 256 * 32);
@@ -2988,19 +3020,14 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
         OTTO_HIP(hipGetLastError());
         OTTO_HIP(hipMemcpyAsync(tot, d_tot, N_TOTALS * 8, hipMemcpyDeviceToHost, s));
     }
-    OTTO_TRY(device_scan(RunCount{c->cnt64.as<uint64_t>()}, (int64_t)n_aids, c->run_start.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+    if (!bucketed)
+        OTTO_TRY(device_scan(RunCount{c->cnt64.as<uint64_t>()}, (int64_t)n_aids, c->run_start.as<uint64_t>(), c->partial.as<uint64_t>(), s));
     OTTO_HIP(hipStreamSynchronize(s));
     c->n_pairs = tot[0];
     c->n_runs = tot[1];
     for (int bin = 0; bin < 3; ++bin) { c->bin_pairs[bin] = tot[2 + bin]; c->bin_runs[bin] = tot[5 + bin]; }
-    OTTO_TRY(c->sorted_desc.ensure((size_t)(c->n_runs ? c->n_runs : 1) * 8, 0, s));
-    if (bucketed) {
-        ba.run_start = c->run_start.as<uint64_t>();
-        ba.sorted_desc = c->sorted_desc.as<uint64_t>();
-        const int lgrid = (int)(ba.nb < 256u * 2u ? ba.nb : 256u * 2u);
-        k_bkt_local<true><<<lgrid, BKT_THREADS, (size_t)12 << ba.sh, s>>>(ba);
-        OTTO_HIP(hipGetLastError());
-    } else if (n_slots) {
+    if (!bucketed && n_slots) {
+        OTTO_TRY(c->sorted_desc.ensure((size_t)(c->n_runs ? c->n_runs : 1) * 8, 0, s));
         int grid = (int)((n_slots + 255) / 256 < 256 * 32 ? (n_slots + 255) / 256 : 256 * 32);
         k_scatter_runs<<<grid, 256, 0, s>>>(c->run_x.as<uint32_t>(), c->run_desc.as<uint64_t>(), c->run_rank.as<uint32_t>(),
                                             n_slots, c->run_start.as<uint64_t>(), c->sorted_desc.as<uint64_t>(), n_aids);
