@@ -103,6 +103,9 @@ __global__ void k_fill_classes(const uint8_t* cls, int64_t n_sess, ClassFill f, 
     if (c < N_WIN_CLASSES) sess_list[f.base[c] + f.pos[c][s]] = (uint32_t)s;
 }
 
+// run_x of a run slot without records (a repeated aid of a window): the index passes skip it without reading its descriptor
+constexpr uint32_t RUN_X_EMPTY = 0xFFFFFFFFu;
+
 struct ExpandArgs {
     const uint32_t* aid;
     const int32_t* ts;
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
             }
         }
         if (g < n) {
-            a.run_x[a.run_base + ebase + g] = aid;
+            a.run_x[a.run_base + ebase + g] = my_cnt ? aid : RUN_X_EMPTY;
             a.run_desc[a.run_base + ebase + g] = my_cnt ? (((a.rec_base + pbase + my_off) << 8) | my_cnt) : 0ull;
         }
         wave_lds_sync();
@@ -340,8 +343,8 @@ __global__ __launch_bounds__(256) void k_expand_fast(ExpandArgs a) {
             }
         }
         if (g < n) {
-            a.run_x[a.run_base + ebase + g] = aid;
             const bool has = rep && d > 1;
+            a.run_x[a.run_base + ebase + g] = has ? aid : RUN_X_EMPTY;
             a.run_desc[a.run_base + ebase + g] = has ? (((a.rec_base + pbase + (uint64_t)below * (d - 1)) << 8) | (d - 1)) : 0ull;
         }
         wave_lds_sync();
@@ -462,7 +465,7 @@ __device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, 
             }
         }
         if (act) {
-            a.run_x[a.run_base + ebase + g] = aid;
+            a.run_x[a.run_base + ebase + g] = (rep && d1) ? aid : RUN_X_EMPTY;
             a.run_desc[a.run_base + ebase + g] = (rep && d1) ? (((a.rec_base + pbase + (uint64_t)below * d1) << 8) | d1) : 0ull;
         }
         wave_lds_sync();
@@ -504,7 +507,7 @@ __device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, 
     }
     if (act) {
         const uint32_t len = rep ? __popc(done) : 0u;
-        a.run_x[a.run_base + ebase + g] = aid;
+        a.run_x[a.run_base + ebase + g] = len ? aid : RUN_X_EMPTY;
         a.run_desc[a.run_base + ebase + g] = len ? (((a.rec_base + pbase + rb) << 8) | len) : 0ull;
     }
     wave_lds_sync();
@@ -639,63 +642,65 @@ struct BktArgs {
     uint32_t n_aids;
     int sh;                        // aids per bucket = 1 << sh
     uint32_t nb;
-    uint32_t* bcount;              // [nb] runs per bucket, then the scatter cursors
-    const uint64_t* bstart;        // [nb + 1]
+    uint32_t* bcnt_blk;            // [nb][split grid] runs per (bucket, split workgroup)
+    const uint64_t* bscan;         // [nb * split grid + 1] its bucket-major exclusive scan: bucket b starts at bscan[b * bstride]
+    uint32_t bstride;              // = split grid
     ulonglong2* tmp;               // bucketed runs {desc, aid_x}
     uint64_t* cnt64;
     const uint64_t* run_start;
     uint64_t* sorted_desc;
 };
 
+// Split without global atomics: workgroup w always takes the same range of consecutive chunks, so the count pass leaves ONE counter
+// per (bucket, workgroup) and their bucket-major scan is every workgroup's private, contiguous piece of every bucket:
+// the scatter pass keeps running cursors in LDS and needs neither a per-chunk histogram nor a cursor bump.
+//   count  : s_cnt = histogram over all the workgroup's chunks (only run_x is read: empty runs carry RUN_X_EMPTY)
+//   scatter: s_cnt[b] = the workgroup's next position in bucket b; one returning LDS atomic per run
 template <bool SCATTER>
 __global__ __launch_bounds__(BKT_THREADS) void k_bkt_split(BktArgs a) {
     __shared__ uint32_t s_cnt[BKT_MAX_NB];
-    __shared__ uint64_t s_base[SCATTER ? BKT_MAX_NB : 1];      // global position of the chunk's piece of bucket b
     const int64_t n_chunks = (a.n_slots + BKT_CHUNK - 1) / BKT_CHUNK;
     constexpr int PER = BKT_CHUNK / BKT_THREADS;
-    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-        for (uint32_t b = threadIdx.x; b < a.nb; b += BKT_THREADS) s_cnt[b] = 0;
-        __syncthreads();
+    for (uint32_t b = threadIdx.x; b < a.nb; b += BKT_THREADS)
+        s_cnt[b] = SCATTER ? (uint32_t)a.bscan[(size_t)b * gridDim.x + blockIdx.x] : 0u;      // absolute position (run slots < 2^32)
+    __syncthreads();
+    // consecutive chunks per workgroup: its pieces of a bucket are written back to back in time, so the 16-byte stores of
+    // neighbouring chunks complete each other's cache lines in L2
+    const int64_t per_wg = (n_chunks + gridDim.x - 1) / gridDim.x;
+    const int64_t ch_end = min(n_chunks, (int64_t)(blockIdx.x + 1) * per_wg);
+    for (int64_t ch = (int64_t)blockIdx.x * per_wg; ch < ch_end; ++ch) {
         const int64_t i0 = ch * BKT_CHUNK + threadIdx.x;
-        uint32_t xs[PER];                    // aid of a non-empty run with a valid aid, else 0xFFFFFFFF
+        uint32_t xs[PER];
         uint64_t ds[SCATTER ? PER : 1];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int64_t i = i0 + (int64_t)u * BKT_THREADS;
-            uint32_t x = 0xFFFFFFFFu;
-            uint64_t d = 0;
+            uint32_t x = RUN_X_EMPTY;
             if (i < a.n_slots) {
-                d = a.run_desc[i];
-                if (d & 0xFFull) x = a.run_x[i];
+                x = a.run_x[i];
+                if (SCATTER) ds[u] = a.run_desc[i];       // requested together with run_x: one round trip per chunk, not two
             }
-            if (x >= a.n_aids) x = 0xFFFFFFFFu;
+            if (x >= a.n_aids) x = RUN_X_EMPTY;
             xs[u] = x;
-            if (SCATTER) ds[u] = d;
-            if (x != 0xFFFFFFFFu) atomicAdd(&s_cnt[x >> a.sh], 1u);
         }
-        __syncthreads();
         if (!SCATTER) {
-            for (uint32_t b = threadIdx.x; b < a.nb; b += BKT_THREADS) {
-                const uint32_t n = s_cnt[b];
-                if (n) atomicAdd(&a.bcount[b], n);
-            }
+#pragma unroll
+            for (int u = 0; u < PER; ++u)
+                if (xs[u] != RUN_X_EMPTY) atomicAdd(&s_cnt[xs[u] >> a.sh], 1u);
         } else {
-            for (uint32_t b = threadIdx.x; b < a.nb; b += BKT_THREADS) {
-                const uint32_t n = s_cnt[b];
-                s_base[b] = n ? a.bstart[b] + atomicAdd(&a.bcount[b], n) : 0ull;     // bcount was reset: it is the bucket cursor now
-                s_cnt[b] = 0;
-            }
-            __syncthreads();
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
-                if (xs[u] != 0xFFFFFFFFu) {
+                if (xs[u] != RUN_X_EMPTY) {
                     const uint32_t b = xs[u] >> a.sh;
-                    const uint64_t pos = s_base[b] + atomicAdd(&s_cnt[b], 1u);
+                    const uint32_t pos = atomicAdd(&s_cnt[b], 1u);
                     a.tmp[pos] = make_ulonglong2(ds[u], (unsigned long long)xs[u]);     // one 16-byte store per run
                 }
             }
         }
+    }
+    if (!SCATTER) {
         __syncthreads();
+        for (uint32_t b = threadIdx.x; b < a.nb; b += BKT_THREADS) a.bcnt_blk[(size_t)b * gridDim.x + blockIdx.x] = s_cnt[b];
     }
 }
 
@@ -712,7 +717,7 @@ __global__ __launch_bounds__(BKT_THREADS) void k_bkt_fused(BktArgs a, uint64_t* 
         const uint32_t x0 = b << a.sh;
         for (uint32_t i = threadIdx.x; i < ab; i += BKT_THREADS) { s_dyn[i] = 0; s_cur[i] = 0; }
         __syncthreads();
-        const uint64_t e0 = a.bstart[b], e1 = a.bstart[b + 1];
+        const uint64_t e0 = a.bscan[(size_t)b * a.bstride], e1 = a.bscan[(size_t)(b + 1) * a.bstride];
         for (uint64_t i0 = e0 + threadIdx.x; i0 < e1; i0 += 4 * BKT_THREADS) {
             uint32_t xl[4];
             uint64_t d[4];
@@ -1343,13 +1348,19 @@ __global__ void k_fill_chunks(ChunkCount f, uint32_t n_aids, const uint64_t* chu
 //   [0] records  [1] runs  [2..4] records per bin  [5..7] runs per bin  [8..10] work items per bin
 //   [11..13] heavy items per layout  [14..16] heavy aids per layout (pilots)  [17] partition chunks
 constexpr int N_TOTALS = 18;
+constexpr int ITEM_BLOCK_AIDS = 2048;      // aids per workgroup of k_aid_totals / k_items_fill (same split in both)
+constexpr int N_ITEM_SCANS = 10;           // totals [8, 18): the counters whose prefixes place the work items
+// block_part (nullable): [gridDim.x][N_ITEM_SCANS] the block's own sums of totals [8, 18) -- k_items_fill adds up the
+// blocks before it instead of running ten device-wide scans.
 __global__ __launch_bounds__(256) void k_aid_totals(const uint64_t* cnt64, const uint8_t* boost, const uint32_t* flag, uint32_t n_aids,
-                                                    uint32_t l_cap, int allow_packed, unsigned long long* totals) {
+                                                    uint32_t l_cap, int allow_packed, unsigned long long* totals,
+                                                    unsigned long long* block_part) {
     __shared__ unsigned long long s_t[4][N_TOTALS];
     unsigned long long t[N_TOTALS];
 #pragma unroll
     for (int q = 0; q < N_TOTALS; ++q) t[q] = 0;
-    for (uint32_t x = blockIdx.x * 256 + threadIdx.x; x < n_aids; x += gridDim.x * 256) {
+    const uint32_t x_end = min(n_aids, (blockIdx.x + 1) * (uint32_t)ITEM_BLOCK_AIDS);
+    for (uint32_t x = blockIdx.x * ITEM_BLOCK_AIDS + threadIdx.x; x < x_end; x += 256) {
         const uint64_t c64 = cnt64[x], n = c64 & CNT_REC_MASK, r = c64 >> CNT_REC_BITS;
         if (n == 0) continue;
         const int b = n <= (uint64_t)S_CAP ? 0 : (n <= (uint64_t)M_CAP ? 1 : 2);
@@ -1375,6 +1386,105 @@ __global__ __launch_bounds__(256) void k_aid_totals(const uint64_t* cnt64, const
     if (threadIdx.x < N_TOTALS) {
         const unsigned long long v = s_t[0][threadIdx.x] + s_t[1][threadIdx.x] + s_t[2][threadIdx.x] + s_t[3][threadIdx.x];
         if (v) atomicAdd(&totals[threadIdx.x], v);
+        if (block_part && threadIdx.x >= N_TOTALS - N_ITEM_SCANS)
+            block_part[(size_t)blockIdx.x * N_ITEM_SCANS + threadIdx.x - (N_TOTALS - N_ITEM_SCANS)] = v;
+    }
+}
+
+// All work lists of a build in ONE launch (replaces ten device-wide scans and seven fill launches): work items of the
+// three bins, the heavy bin's processing order per layout (pilots first), the partition-pass chunks and litem_start.
+// A workgroup owns the same ITEM_BLOCK_AIDS aids as in k_aid_totals; its base prefixes are the sums of the earlier
+// blocks' partials, the prefixes inside the block are block scans in aid order.
+struct ItemFillArgs {
+    const uint64_t* cnt64;
+    const uint8_t* boost;
+    uint32_t n_aids;
+    uint32_t l_cap;
+    int allow_packed;
+    const unsigned long long* block_part;
+    uint64_t* items[3];
+    uint32_t* order[3];
+    uint64_t n_pilots[3];
+    uint64_t* chunks;
+    uint64_t* litem_start;     // [n_aids + 1]
+};
+__global__ __launch_bounds__(256) void k_items_fill(ItemFillArgs a) {
+    __shared__ unsigned long long s_base[N_ITEM_SCANS];
+    __shared__ uint64_t s_sc[256 / 64 + 1];
+    if (threadIdx.x < N_ITEM_SCANS) s_base[threadIdx.x] = 0;
+    __syncthreads();
+    {
+        unsigned long long acc[N_ITEM_SCANS];
+#pragma unroll
+        for (int q = 0; q < N_ITEM_SCANS; ++q) acc[q] = 0;
+        for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256)
+#pragma unroll
+            for (int q = 0; q < N_ITEM_SCANS; ++q) acc[q] += a.block_part[(size_t)j * N_ITEM_SCANS + q];
+#pragma unroll
+        for (int q = 0; q < N_ITEM_SCANS; ++q) {
+            unsigned long long v = acc[q];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane_id() == 0 && v) atomicAdd(&s_base[q], v);
+        }
+    }
+    __syncthreads();
+    // running prefixes (order of totals [8, 18)): [0..2] items per bin, [3..5] heavy items per layout, [6..8] heavy aids per layout, [9] chunks
+    uint64_t run[N_ITEM_SCANS];
+#pragma unroll
+    for (int q = 0; q < N_ITEM_SCANS; ++q) run[q] = s_base[q];
+    for (int it = 0; it < ITEM_BLOCK_AIDS / 256; ++it) {
+        const uint32_t x = blockIdx.x * ITEM_BLOCK_AIDS + it * 256 + threadIdx.x;
+        int b = -1, mode = -1;
+        uint64_t items = 0, nch = 0;
+        if (x < a.n_aids) {
+            const uint64_t c64 = a.cnt64[x], n = c64 & CNT_REC_MASK;
+            if (n) {
+                b = n <= (uint64_t)S_CAP ? 0 : (n <= (uint64_t)M_CAP ? 1 : 2);
+                items = 1;
+                if (b == 2) {
+                    mode = heavy_mode(c64, a.allow_packed, a.l_cap);
+                    const int lg = l_log2r(c64, a.boost[x], a.l_cap, a.allow_packed);
+                    items = 1ull << lg;
+                    if (lg) nch = ((c64 >> CNT_REC_BITS) + PART_CHUNK_RUNS - 1) / PART_CHUNK_RUNS;
+                }
+            }
+        }
+        // five 0/1 counters travel in one word (12 bits each: at most 256 per round)
+        const uint64_t small = (uint64_t)(b == 0) | (uint64_t)(b == 1) << 12 | (uint64_t)(mode == 0) << 24 | (uint64_t)(mode == 1) << 36 |
+                               (uint64_t)(mode == 2) << 48;
+        uint64_t tot_small, tot_l, tot_m[3], tot_c;
+        const uint64_t ex_small = block_excl_scan<uint64_t, 256>(small, s_sc, &tot_small);
+        const uint64_t ex_l = block_excl_scan<uint64_t, 256>(b == 2 ? items : 0ull, s_sc, &tot_l);
+        uint64_t ex_m[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) ex_m[m] = block_excl_scan<uint64_t, 256>(mode == m ? items : 0ull, s_sc, &tot_m[m]);
+        const uint64_t ex_c = block_excl_scan<uint64_t, 256>(nch, s_sc, &tot_c);
+        if (b == 0) a.items[0][run[0] + (ex_small & 0xFFF)] = (uint64_t)x;
+        if (b == 1) a.items[1][run[1] + ((ex_small >> 12) & 0xFFF)] = (uint64_t)x;
+        const uint64_t s = run[2] + ex_l;
+        if (x < a.n_aids) a.litem_start[x] = s;
+        if (x == a.n_aids - 1) a.litem_start[a.n_aids] = s + (b == 2 ? items : 0ull);
+        if (b == 2) {
+            uint64_t lg = 0;
+            while ((1ull << lg) < items) ++lg;
+            for (uint64_t p = 0; p < items; ++p) a.items[2][s + p] = (uint64_t)x | (p << 26) | (lg << 50);
+            const uint64_t r = run[6 + mode] + ((ex_small >> (24 + 12 * mode)) & 0xFFF);
+            const uint64_t sm = run[3 + mode] + ex_m[mode];
+            uint32_t* ord = a.order[mode];
+            ord[r] = (uint32_t)s;
+            for (uint64_t p = 1; p < items; ++p) ord[a.n_pilots[mode] + sm + p - r - 1] = (uint32_t)(s + p);
+            const uint64_t cs = run[9] + ex_c;
+            for (uint64_t q = 0; q < nch; ++q) a.chunks[cs + q] = (uint64_t)x | (q << 26);
+        }
+        run[0] += tot_small & 0xFFF;
+        run[1] += (tot_small >> 12) & 0xFFF;
+        run[2] += tot_l;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            run[6 + m] += (tot_small >> (24 + 12 * m)) & 0xFFF;
+            run[3 + m] += tot_m[m];
+        }
+        run[9] += tot_c;
     }
 }
 
@@ -2613,7 +2723,7 @@ struct HdrLen {
 __global__ void k_import(const uint32_t* hdr, int64_t n_runs, const uint64_t* rec_pos, uint64_t rec_base,
                          uint64_t run_base, uint32_t* run_x, uint64_t* run_desc) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += (int64_t)gridDim.x * blockDim.x) {
-        run_x[run_base + i] = hdr[2 * i];
+        run_x[run_base + i] = hdr[2 * i + 1] ? hdr[2 * i] : RUN_X_EMPTY;
         run_desc[run_base + i] = ((rec_base + rec_pos[i]) << 8) | (uint64_t)hdr[2 * i + 1];
     }
 }
@@ -2645,7 +2755,7 @@ struct otto_covis_ctx {
     uint64_t bin_runs[3] = {0, 0, 0};
     uint64_t n_pairs = 0, n_runs = 0;
     // partition pass of heavy aids
-    DevBuf litem_start, chunks, pcount, pcursor, pstart, prec, ptw;
+    DevBuf litem_start, chunks, pcount, pcursor, pstart, prec, ptw, item_part;
     uint64_t n_chunks = 0;
     int partition = 1;
     bool exact_round = false;      // set by finalize for the rounds that redo flagged aids
@@ -2723,7 +2833,7 @@ extern "C" void otto_covis_destroy(otto_covis_ctx* c) {
                      &c->sess_list, &c->cls_byte,
                      &c->run_start, &c->run_rank, &c->sorted_desc, &c->item_start, &c->boost, &c->flag, &c->counters,
                      &c->items[0], &c->items[1], &c->items[2], &c->part_y, &c->part_w, &c->tau_w, &c->tau_y, &c->lorder[1][0], &c->lorder[1][1], &c->lorder[1][2], &c->lorder[2][0], &c->lorder[2][1], &c->lorder[2][2], &c->lrank, &c->lmode_start, &c->bcount, &c->bstart, &c->tmp_runs, &c->exp_run_pos, &c->exp_rec_pos, &c->exp_totals,
-                     &c->litem_start, &c->chunks, &c->pcount, &c->pcursor, &c->pstart, &c->prec, &c->ptw};
+                     &c->litem_start, &c->chunks, &c->pcount, &c->pcursor, &c->pstart, &c->prec, &c->ptw, &c->item_part};
     for (DevBuf* b : all) b->release();
     if (c->ev_ok)
         for (int i = 0; i < 2 * OTTO_COVIS_T_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
@@ -2972,34 +3082,32 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
     memset(&ba, 0, sizeof ba);
     ba.sh = aid_bits > 22 ? aid_bits - 12 : 10;
     ba.nb = (uint32_t)(((uint64_t)n_aids + (1ull << ba.sh) - 1) >> ba.sh);
-    const bool bucketed = c->bucket_index && n_slots > 0 && ba.nb <= (uint32_t)BKT_MAX_NB && ba.sh <= 12;   // <= 48 KB of LDS per bucket
+    const bool bucketed = c->bucket_index && n_slots > 0 && n_slots < (1ll << 32) && ba.nb <= (uint32_t)BKT_MAX_NB && ba.sh <= 12;   // <= 48 KB of LDS per bucket
     if (bucketed) {
         ba.run_x = c->run_x.as<uint32_t>(); ba.run_desc = c->run_desc.as<uint64_t>();
         ba.n_slots = n_slots; ba.n_aids = n_aids;
-        OTTO_TRY(c->bcount.ensure((size_t)ba.nb * 4, 0, s));
-        OTTO_TRY(c->bstart.ensure((size_t)(ba.nb + 1) * 8, 0, s));
-        OTTO_HIP(hipMemsetAsync(c->bcount.p, 0, (size_t)ba.nb * 4, s));
-        ba.bcount = c->bcount.as<uint32_t>();
         const int64_t n_chunks = (n_slots + BKT_CHUNK - 1) / BKT_CHUNK;
         const int sgrid = (int)(n_chunks < 256 * 2 ? n_chunks : 256 * 2);
-        kname(c, OTTO_COVIS_T_INDEX, "k_bkt_split<false/true> + k_bkt_fused + k_aid_totals + k_scan_* + k_fill_*");
+        const int64_t n_cells = (int64_t)ba.nb * sgrid;
+        OTTO_TRY(c->bcount.ensure((size_t)n_cells * 4, 0, s));
+        OTTO_TRY(c->bstart.ensure((size_t)(n_cells + 1) * 8, 0, s));
+        OTTO_TRY(c->partial.ensure(scan_partial_bytes(n_cells > (int64_t)n_aids ? n_cells : (int64_t)n_aids), 0, s));
+        ba.bcnt_blk = c->bcount.as<uint32_t>();
+        ba.bscan = c->bstart.as<uint64_t>();
+        ba.bstride = (uint32_t)sgrid;
+        kname(c, OTTO_COVIS_T_INDEX, "k_bkt_split<false/true> + k_bkt_fused + k_aid_totals + k_items_fill");
         k_bkt_split<false><<<sgrid, BKT_THREADS, 0, s>>>(ba);
         OTTO_HIP(hipGetLastError());
-        OTTO_TRY(device_scan(BktCount{ba.bcount}, (int64_t)ba.nb, c->bstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
-        uint64_t n_runs_b = 0;
-        OTTO_HIP(hipMemcpyAsync(&n_runs_b, c->bstart.as<uint64_t>() + ba.nb, 8, hipMemcpyDeviceToHost, s));
-        OTTO_HIP(hipStreamSynchronize(s));
-        OTTO_TRY(c->tmp_runs.ensure((size_t)(n_runs_b ? n_runs_b : 1) * 16, 0, s));
-        OTTO_HIP(hipMemsetAsync(c->bcount.p, 0, (size_t)ba.nb * 4, s));
-        ba.bstart = c->bstart.as<uint64_t>();
+        OTTO_TRY(device_scan(BktCount{ba.bcnt_blk}, n_cells, c->bstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+        // non-empty runs <= run slots: the buffers are sized by the bound, so the split needs no host round trip
+        OTTO_TRY(c->tmp_runs.ensure((size_t)n_slots * 16, 0, s));
         ba.tmp = c->tmp_runs.as<ulonglong2>();
         k_bkt_split<true><<<sgrid, BKT_THREADS, 0, s>>>(ba);
         OTTO_HIP(hipGetLastError());
         ba.cnt64 = c->cnt64.as<uint64_t>();
         const int lgrid = (int)(ba.nb < 256u * 2u ? ba.nb : 256u * 2u);
-        // the split left every bucket's runs contiguous: the total is known, counting / scanning / placing is one launch
-        c->n_runs = n_runs_b;
-        OTTO_TRY(c->sorted_desc.ensure((size_t)(c->n_runs ? c->n_runs : 1) * 8, 0, s));
+        // the split left every bucket's runs contiguous: counting / scanning / placing is one launch
+        OTTO_TRY(c->sorted_desc.ensure((size_t)n_slots * 8, 0, s));
         ba.sorted_desc = c->sorted_desc.as<uint64_t>();
         k_bkt_fused<<<lgrid, BKT_THREADS, (size_t)12 << ba.sh, s>>>(ba, c->run_start.as<uint64_t>());
         OTTO_HIP(hipGetLastError());
@@ -3012,11 +3120,13 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
     }
     // every total the build needs on the host in one reduction + ONE synchronisation (boost / flag are zero here)
     uint64_t tot[N_TOTALS];
+    const int item_blocks = (int)((n_aids + ITEM_BLOCK_AIDS - 1) / ITEM_BLOCK_AIDS);
     {
         unsigned long long* d_tot = c->counters.as<unsigned long long>() + 4;        // counters: 64 u64 words, [4, 4 + N_TOTALS) here
         OTTO_HIP(hipMemsetAsync(d_tot, 0, N_TOTALS * 8, s));
-        k_aid_totals<<<256 * 4, 256, 0, s>>>(c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(), c->flag.as<uint32_t>(), n_aids, c->l_cap,
-                                             c->packed_heavy, d_tot);
+        OTTO_TRY(c->item_part.ensure((size_t)item_blocks * N_ITEM_SCANS * 8, 0, s));
+        k_aid_totals<<<item_blocks, 256, 0, s>>>(c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(), c->flag.as<uint32_t>(), n_aids, c->l_cap,
+                                                 c->packed_heavy, d_tot, c->item_part.as<unsigned long long>());
         OTTO_HIP(hipGetLastError());
         OTTO_HIP(hipMemcpyAsync(tot, d_tot, N_TOTALS * 8, hipMemcpyDeviceToHost, s));
     }
@@ -3033,7 +3143,33 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
                                             n_slots, c->run_start.as<uint64_t>(), c->sorted_desc.as<uint64_t>(), n_aids);
         OTTO_HIP(hipGetLastError());
     }
-    for (int bin = 0; bin < 3; ++bin) OTTO_TRY(build_items(c, bin, 0, s, c->packed_heavy, tot));
+    {   // all work lists in one launch (build_items is the per-bin form the overflow retries use)
+        ItemFillArgs fa;
+        memset(&fa, 0, sizeof fa);
+        fa.cnt64 = c->cnt64.as<uint64_t>(); fa.boost = c->boost.as<uint8_t>(); fa.n_aids = n_aids; fa.l_cap = c->l_cap;
+        fa.allow_packed = c->packed_heavy; fa.block_part = c->item_part.as<unsigned long long>();
+        for (int bin = 0; bin < 3; ++bin) {
+            OTTO_REQUIRE(tot[8 + bin] < (1ull << 32), "too many work items (%llu)", (unsigned long long)tot[8 + bin]);
+            c->n_items[bin] = tot[8 + bin];
+            OTTO_TRY(c->items[bin].ensure((size_t)(tot[8 + bin] ? tot[8 + bin] : 1) * 8, 0, s));
+            fa.items[bin] = c->items[bin].as<uint64_t>();
+        }
+        c->items_allow_packed = c->packed_heavy;
+        for (int mode = 0; mode < 3; ++mode) {
+            c->n_order[2][mode] = tot[11 + mode];
+            OTTO_TRY(c->lorder[2][mode].ensure((size_t)(tot[11 + mode] ? tot[11 + mode] : 1) * 4, 0, s));
+            fa.order[mode] = c->lorder[2][mode].as<uint32_t>();
+            fa.n_pilots[mode] = tot[14 + mode];
+        }
+        OTTO_REQUIRE(tot[17] < (1ull << 32), "too many partition chunks");
+        c->n_chunks = tot[17];
+        OTTO_TRY(c->chunks.ensure((size_t)(tot[17] ? tot[17] : 1) * 8, 0, s));
+        fa.chunks = c->chunks.as<uint64_t>();
+        OTTO_TRY(c->litem_start.ensure((size_t)(n_aids + 1) * 8, 0, s));
+        fa.litem_start = c->litem_start.as<uint64_t>();
+        k_items_fill<<<item_blocks, 256, 0, s>>>(fa);
+        OTTO_HIP(hipGetLastError());
+    }
     tend(c, OTTO_COVIS_T_INDEX, s);
     c->retries = 0;
     c->index_valid = true;
