@@ -37,6 +37,7 @@ extern "C" {
 #define OTTO_CAND_SRC_CC 1
 #define OTTO_CAND_SRC_CO 2
 #define OTTO_CAND_SRC_LAST 3 /* the aid of the session's last event: the fastText / Annoy neighbour term               */
+#define OTTO_CAND_SRC_C 4    /* np.unique(aids[types == 0]): click aids, ascending (covisitation/inference.py:147)         */
 
 typedef struct otto_cand_params {
     uint32_t n_aids;
@@ -60,6 +61,14 @@ typedef struct otto_cand_params {
  */
 int otto_cand_lookup(const otto_cand_params* params, const uint32_t* d_aid, const uint8_t* d_type, const int64_t* d_sess_off,
                      int64_t n_sess, int32_t* d_cand, int32_t* d_count, int32_t* d_n, void* stream);
+
+/*
+ * The same lookup for the recency branch below (otto_recency_predictions): the session's own aids are taken OUT of the
+ * selection before most_common (so d_cand holds the n_common best aids that are not in the session) and the Counter count of
+ * every session aid is written to d_self_count [n_events] at each event holding it (0: the aid is not in the concatenation).
+ */
+int otto_cand_lookup_self(const otto_cand_params* params, const uint32_t* d_aid, const uint8_t* d_type, const int64_t* d_sess_off,
+                          int64_t n_sess, int32_t* d_cand, int32_t* d_count, int32_t* d_n, int32_t* d_self_count, void* stream);
 
 /*
  * Final predictions of the standalone covisitation model, src/covisitation/inference.py:236-241 (validation) / :431-436:
@@ -100,6 +109,43 @@ typedef struct otto_recency_params {
 int otto_recency_candidates(const otto_recency_params* params, const uint32_t* d_aid, const uint8_t* d_type,
                             const int64_t* d_sess_off, int64_t n_sess, int64_t n_events, int32_t* d_out_aid, double* d_out_w,
                             int32_t* d_n, void* stream);
+
+/*
+ * Predictions of the recency branch of the standalone model, src/covisitation/inference.py:143-199 (sessions with at least 20
+ * unique aids, :128-131; same code :338-394 for the submission). Per session and target (click / cart / order):
+ *     Counter[aid] += w[i] * type_coef[type_i]        the recency weights above, in event order                    (:152-163)
+ *     Counter[aid] += bump  for the 45 nearest neighbours of the last aid                                          (:166-171)
+ *     Counter[aid] += bump  for every entry of the concatenated top lists of the target's source aids             (:174-194)
+ *     Counter.most_common(20)  -- weight desc, ties by first insertion (session aids in event order, then the neighbours,
+ *                                 then the list entries in concatenation order)                                    (:179,187,195)
+ * The reference's bumps are 0.05 / 0.05 / 0.15 (the neighbour bump of a target equals its list bump), its curves (0.1, 1) for
+ * clicks and (0.5, 1) for carts and orders, type_coef = {0: 1, 1: 9, 2: 6} (:72), the lists time_weighted over the sorted
+ * unique click aids, cart_weighted over the click + cart aids, cart_order over the cart + order aids.
+ * Inputs per target t: the outputs of otto_cand_lookup_self for the recipe [(neighbours, LAST), (list matrix, source)]:
+ * d_cand[t] / d_count[t] [n_sess][n_common] (aids outside the session with their counts, most_common order), d_n_cand[t]
+ * [n_sess], d_self_count[t] [n_events]. A weight is the float64 sum in the reference's order: base weight, then `count`
+ * additions of the bump one by one. Outputs: d_pred [n_targets][n_sess][n_pred] int32 (-1 padded), d_weight (nullable, same
+ * shape, float64), d_n [n_targets][n_sess] int32; sessions with fewer than min_unique unique aids are skipped (d_n = -1).
+ */
+#define OTTO_RECENCY_MAX_TARGETS 3
+typedef struct otto_recency_pred_params {
+    int32_t n_targets;
+    double start[OTTO_RECENCY_MAX_TARGETS];
+    double stop[OTTO_RECENCY_MAX_TARGETS];
+    double bump[OTTO_RECENCY_MAX_TARGETS];
+    double type_coef[3];
+    int32_t n_common;                                  /* row length of d_cand / d_count                    */
+    int32_t n_pred;                                    /* most_common(n_pred), <= 64                        */
+    int32_t min_unique;                                /* 20 in the reference                               */
+    const int32_t* d_cand[OTTO_RECENCY_MAX_TARGETS];
+    const int32_t* d_count[OTTO_RECENCY_MAX_TARGETS];
+    const int32_t* d_n_cand[OTTO_RECENCY_MAX_TARGETS];
+    const int32_t* d_self_count[OTTO_RECENCY_MAX_TARGETS];
+} otto_recency_pred_params;
+
+int otto_recency_predictions(const otto_recency_pred_params* params, const uint32_t* d_aid, const uint8_t* d_type,
+                             const int64_t* d_sess_off, int64_t n_sess, int32_t* d_pred, double* d_weight, int32_t* d_n,
+                             void* stream);
 
 #ifdef __cplusplus
 }

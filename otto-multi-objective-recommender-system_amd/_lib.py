@@ -49,6 +49,24 @@ class RecencyParams(C.Structure):
     ]
 
 
+class RecencyPredParams(C.Structure):
+    # mirrors otto_recency_pred_params (include/otto_cand.h)
+    _fields_ = [
+        ('n_targets', C.c_int32),
+        ('start', C.c_double * 3),
+        ('stop', C.c_double * 3),
+        ('bump', C.c_double * 3),
+        ('type_coef', C.c_double * 3),
+        ('n_common', C.c_int32),
+        ('n_pred', C.c_int32),
+        ('min_unique', C.c_int32),
+        ('d_cand', C.c_void_p * 3),
+        ('d_count', C.c_void_p * 3),
+        ('d_n_cand', C.c_void_p * 3),
+        ('d_self_count', C.c_void_p * 3),
+    ]
+
+
 class CovisParams(C.Structure):
     # mirrors otto_covis_params (include/otto_covis.h)
     _fields_ = [
@@ -91,6 +109,8 @@ SIGNATURES = {
     'otto_debug_calibrate': (_i32, [_vp, _i64, _i32, _vp]),
     # include/otto_cand.h
     'otto_cand_lookup': (_i32, [C.POINTER(CandParams), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    'otto_cand_lookup_self': (_i32, [C.POINTER(CandParams), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    'otto_recency_predictions': (_i32, [C.POINTER(RecencyPredParams), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     'otto_cand_predictions': (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     'otto_recency_candidates': (_i32, [C.POINTER(RecencyParams), _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     # include/otto_events.h

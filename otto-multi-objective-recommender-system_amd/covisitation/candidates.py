@@ -4,7 +4,7 @@ import ctypes as C
 
 from .. import _lib
 
-SOURCES = {'U': 0, 'CC': 1, 'CO': 2, 'LAST': 3}
+SOURCES = {'U': 0, 'CC': 1, 'CO': 2, 'LAST': 3, 'C': 4}
 # recipes of covisitation_candidate_generation.py:127,133,138
 CLICK_RECIPE = (('time_weighted', 'U'), ('click_weighted', 'CC'), ('cart_weighted', 'CC'), ('click_cart', 'CC'), ('cart_order', 'CC'))
 CART_RECIPE = (('time_weighted', 'U'), ('cart_weighted', 'CC'), ('cart_order', 'CC'))
@@ -17,9 +17,11 @@ INFERENCE_CART_RECIPE = CART_RECIPE + (('neighbours', 'LAST'),)
 INFERENCE_ORDER_RECIPE = INFERENCE_CART_RECIPE
 
 
-def candidate_lookup(aid, typ, sess_off, matrices, recipe, n_common=100):
+def candidate_lookup(aid, typ, sess_off, matrices, recipe, n_common=100, self_counts=False):
     """``matrices``: {kind: (aid_y int32 [n_aids,k], W, n int32 [n_aids])} as returned by ``CovisBuilder.finalize``.
-    Returns (cand int32 [S, n_common] (-1 padded), count int32 [S, n_common], n int32 [S]) on the device."""
+    Returns (cand int32 [S, n_common] (-1 padded), count int32 [S, n_common], n int32 [S]) on the device.
+    ``self_counts``: the session's own aids leave the selection BEFORE most_common and their Counter counts come back as a
+    fourth tensor int32 [E] (one value per event; ``otto_cand_lookup_self``, used by :func:`recency_predictions`)."""
     import torch
     dev = aid.device
     if dev.type != 'cuda':
@@ -53,6 +55,13 @@ def candidate_lookup(aid, typ, sess_off, matrices, recipe, n_common=100):
         if x.dtype != dt or not x.is_contiguous():
             raise ValueError(f'{name}: expected contiguous {dt}')
     with torch.cuda.device(dev):
+        if self_counts:
+            own = torch.zeros(max(aid.numel(), 1), dtype=torch.int32, device=dev)
+            _lib.check(_lib.lib().otto_cand_lookup_self(C.byref(p), C.c_void_p(aid.data_ptr()), C.c_void_p(typ.data_ptr()),
+                                                        C.c_void_p(sess_off.data_ptr()), S, C.c_void_p(cand.data_ptr()),
+                                                        C.c_void_p(count.data_ptr()), C.c_void_p(n_out.data_ptr()), C.c_void_p(own.data_ptr()),
+                                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), 'otto_cand_lookup_self')
+            return cand, count, n_out, own[:aid.numel()]
         _lib.check(_lib.lib().otto_cand_lookup(C.byref(p), C.c_void_p(aid.data_ptr()), C.c_void_p(typ.data_ptr()),
                                                C.c_void_p(sess_off.data_ptr()), S, C.c_void_p(cand.data_ptr()),
                                                C.c_void_p(count.data_ptr()), C.c_void_p(n_out.data_ptr()),
@@ -116,3 +125,52 @@ def recency_candidates(aid, typ, sess_off, curves=RECENCY_CURVES, type_coef=RECE
                                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
                    'otto_recency_candidates')
     return cand, w, n_out
+
+
+# the recency branch of the standalone model (src/covisitation/inference.py:143-199): per target the recency curve, the bump of
+# a neighbour / list entry, the list matrix and the source aids whose lists are concatenated; type coefficients of :72
+INFERENCE_RECENCY_TARGETS = (
+    {'curve': (0.1, 1.0), 'bump': 0.05, 'matrix': 'time_weighted', 'source': 'C'},      # clicks  (:152,168,174-179)
+    {'curve': (0.5, 1.0), 'bump': 0.05, 'matrix': 'cart_weighted', 'source': 'CC'},     # carts   (:153,169,182-187)
+    {'curve': (0.5, 1.0), 'bump': 0.15, 'matrix': 'cart_order', 'source': 'CO'},        # orders  (:154,170,190-195)
+)
+INFERENCE_TYPE_COEFFICIENT = (1.0, 9.0, 6.0)
+
+
+def recency_predictions(aid, typ, sess_off, matrices, targets=INFERENCE_RECENCY_TARGETS, type_coef=INFERENCE_TYPE_COEFFICIENT,
+                        neighbours='neighbours', min_unique=20, n_pred=20, n_common=None):
+    """Predictions of the sessions the reference routes to its recency branch (at least ``min_unique`` unique aids,
+    ``src/covisitation/inference.py:128-131,143-199``): recency-weighted Counter of the session's aids, + bump for the
+    nearest neighbours of the last aid (``matrices[neighbours]``; None: no neighbour term) and for every entry of the
+    target's concatenated top lists, ``most_common(n_pred)``. Returns (pred int32 [T, S, n_pred] (-1 padded), weight float64
+    [T, S, n_pred], n int32 [T, S]; n = -1 for sessions with fewer unique aids, which the covisitation branch predicts)."""
+    import torch
+    dev = aid.device
+    if dev.type != 'cuda':
+        raise _lib.OttoError('recency_predictions needs a ROCm device (no CPU fallback)')
+    if not 1 <= len(targets) <= 3:
+        raise ValueError('1 to 3 targets')
+    n_common = int(n_common or n_pred)
+    S = sess_off.numel() - 1
+    p = _lib.RecencyPredParams()
+    p.n_targets, p.n_common, p.n_pred, p.min_unique = len(targets), n_common, int(n_pred), int(min_unique)
+    for i in range(3):
+        p.type_coef[i] = float(type_coef[i])
+    keep = []
+    for t, tg in enumerate(targets):
+        recipe = ((neighbours, 'LAST'),) if neighbours is not None else ()
+        recipe = recipe + ((tg['matrix'], tg['source']),)
+        cand, count, n_c, own = candidate_lookup(aid, typ, sess_off, matrices, recipe, n_common=n_common, self_counts=True)
+        keep.append((cand, count, n_c, own))
+        p.start[t], p.stop[t], p.bump[t] = float(tg['curve'][0]), float(tg['curve'][1]), float(tg['bump'])
+        p.d_cand[t], p.d_count[t], p.d_n_cand[t], p.d_self_count[t] = cand.data_ptr(), count.data_ptr(), n_c.data_ptr(), own.data_ptr()
+    T = len(targets)
+    pred = torch.empty((T, S, n_pred), dtype=torch.int32, device=dev)
+    weight = torch.empty((T, S, n_pred), dtype=torch.float64, device=dev)
+    n_out = torch.empty((T, S), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().otto_recency_predictions(C.byref(p), C.c_void_p(aid.data_ptr()), C.c_void_p(typ.data_ptr()),
+                                                       C.c_void_p(sess_off.data_ptr()), S, C.c_void_p(pred.data_ptr()),
+                                                       C.c_void_p(weight.data_ptr()), C.c_void_p(n_out.data_ptr()),
+                                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), 'otto_recency_predictions')
+    return pred, weight, n_out

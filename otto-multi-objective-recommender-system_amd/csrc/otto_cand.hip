@@ -33,6 +33,7 @@ struct CandArgs {
     int32_t* n_out;
     uint32_t* err;
     int lo_len, hi_len;            // this launch handles sessions with lo_len <= events <= hi_len
+    int32_t* self_count;           // nullable: [n_events] Counter count of every event's aid; the session's aids then leave the selection
 };
 
 __device__ __forceinline__ uint64_t cand_key(uint64_t count, uint32_t fp, uint32_t y) {
@@ -50,9 +51,9 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
     static_assert(CD_THREADS >= OTTO_CAND_MAX_COMMON && CD_NW >= 2, "one carried entry per thread, two compaction waves");
     __shared__ uint32_t s_aid[CD_MAXL];
     __shared__ uint8_t s_ty[CD_MAXL];
-    __shared__ uint8_t s_flag[CD_MAXL];               // bit0 last occurrence, bit1 first click/cart, bit2 first cart/order
-    __shared__ uint32_t s_src[4][CD_MAXL];            // U, CC, CO, LAST (the last event's aid: a single source)
-    __shared__ uint32_t s_nsrc[4];
+    __shared__ uint8_t s_flag[CD_MAXL];               // bit0 last occurrence, bit1 first click/cart, bit2 first cart/order, bit3 first click
+    __shared__ uint32_t s_src[5][CD_MAXL];            // U, CC, CO, LAST (the last event's aid: a single source), C
+    __shared__ uint32_t s_nsrc[5];
     __shared__ uint32_t s_base[CD_MAXQ];               // position of list q in the concatenation | len << 24
     __shared__ unsigned long long s_tab[CD_T];        // aid << 32 | count
     __shared__ uint32_t s_fp[CD_T];                    // first position
@@ -76,35 +77,40 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
         }
         // ---- A ----------------------------------------------------------------------------------------
         for (int i = tid; i < n; i += CD_THREADS) { s_aid[i] = a.aid[lo + i]; s_ty[i] = a.type[lo + i]; }
-        if (tid < 3) s_nsrc[tid] = 0;
+        if (tid < 3 || tid == 4) s_nsrc[tid] = 0;
         if (tid == 3) { s_nsrc[3] = n > 0 ? 1u : 0u; s_src[3][0] = n > 0 ? a.aid[lo + n - 1] : 0u; }
+        if (a.self_count)
+            for (int i = tid; i < n; i += CD_THREADS) a.self_count[lo + i] = 0;
         for (int i = tid; i < NC; i += CD_THREADS) s_sel[i] = 0;
         __syncthreads();
         for (int i = tid; i < n; i += CD_THREADS) {
             const uint32_t ai = s_aid[i];
             const uint32_t ti = s_ty[i];
-            bool last = true, fcc = ti <= 1, fco = ti >= 1;
+            bool last = true, fcc = ti <= 1, fco = ti >= 1, fc = ti == 0;
             for (int j = 0; j < n; ++j) {
                 if (s_aid[j] != ai) continue;
                 if (j > i) last = false;
                 if (j < i && s_ty[j] <= 1) fcc = false;
                 if (j < i && s_ty[j] >= 1) fco = false;
+                if (j < i && s_ty[j] == 0) fc = false;
             }
-            s_flag[i] = (uint8_t)((last ? 1 : 0) | (fcc ? 2 : 0) | (fco ? 4 : 0));
+            s_flag[i] = (uint8_t)((last ? 1 : 0) | (fcc ? 2 : 0) | (fco ? 4 : 0) | (fc ? 8 : 0));
         }
         __syncthreads();
         for (int i = tid; i < n; i += CD_THREADS) {
             const uint32_t ai = s_aid[i], fl = s_flag[i];
-            uint32_t ru = 0, rcc = 0, rco = 0;
+            uint32_t ru = 0, rcc = 0, rco = 0, rc = 0;
             for (int j = 0; j < n; ++j) {
                 const uint32_t fj = s_flag[j], aj = s_aid[j];
                 ru += (j > i) & (fj & 1u);
                 rcc += ((fj >> 1) & 1u) & (aj < ai);
                 rco += ((fj >> 2) & 1u) & (aj < ai);
+                rc += ((fj >> 3) & 1u) & (aj < ai);
             }
             if (fl & 1u) { s_src[0][ru] = ai; atomicAdd(&s_nsrc[0], 1u); }
             if (fl & 2u) { s_src[1][rcc] = ai; atomicAdd(&s_nsrc[1], 1u); }
             if (fl & 4u) { s_src[2][rco] = ai; atomicAdd(&s_nsrc[2], 1u); }
+            if (fl & 8u) { s_src[4][rc] = ai; atomicAdd(&s_nsrc[4], 1u); }
         }
         __syncthreads();
         // ---- B ----------------------------------------------------------------------------------------
@@ -187,6 +193,32 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
             }
             __syncthreads();
             if (s_ovf) { again = true; break; }
+            if (a.self_count) {
+                // the session's own aids: report their counts, then take them out of the selection (count 0 = tombstone: the
+                // slot stays occupied for the probes of the other aids)
+                auto find = [&](uint32_t x) -> int {
+                    const uint32_t h = x * 0x9E3779B1u;
+                    if (lgR != 0 && ((h >> (32 - lt - lgR)) & (R - 1u)) != part) return -1;
+                    uint32_t slot = h >> (32 - lt);
+                    for (int probe = 0; probe < Teff; ++probe) {
+                        const unsigned long long v = s_tab[slot];
+                        if (v == CD_EMPTY) return -1;
+                        if ((uint32_t)(v >> 32) == x) return (int)slot;
+                        slot = (slot + 1) & (uint32_t)(Teff - 1);
+                    }
+                    return -1;
+                };
+                for (int i = tid; i < n; i += CD_THREADS) {
+                    const int sl = find(s_aid[i]);
+                    if (sl >= 0) a.self_count[lo + i] = (int32_t)(s_tab[sl] & 0xFFFFFFFFull);
+                }
+                __syncthreads();
+                for (uint32_t j = tid; j < s_nsrc[0]; j += CD_THREADS) {
+                    const int sl = find(s_src[0][j]);
+                    if (sl >= 0) s_tab[sl] &= 0xFFFFFFFF00000000ull;
+                }
+                __syncthreads();
+            }
             // candidates of this lane: its table slots and (carried over from earlier partitions) two entries of s_sel
             auto cand_of = [&](int q) -> KeyN {
                 KeyN k;
@@ -194,7 +226,7 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
                 if (q < mpl) {
                     const int i = q * CD_THREADS + tid;
                     const unsigned long long v = s_tab[i];
-                    if (v != CD_EMPTY) k.c = cand_key(v & 0xFFFFFFFFull, s_fp[i], (uint32_t)(v >> 32));
+                    if (v != CD_EMPTY && (v & 0xFFFFFFFFull) != 0) k.c = cand_key(v & 0xFFFFFFFFull, s_fp[i], (uint32_t)(v >> 32));
                 } else {
                     const int i = tid + (q - mpl) * CD_THREADS;
                     if (part > 0 && i < NC) k.c = s_sel[i];
@@ -433,6 +465,126 @@ __global__ __launch_bounds__(THREADS) void k_recency(RecencyArgs a) {
     }
 }
 
+// ---- recency branch of the standalone model (covisitation/inference.py:143-199) ----------------------------------------
+// One workgroup per session with at least min_unique unique aids. Entries of a target's Counter: the session's first
+// occurrences (insertion order = event order; weight = recency sum, then `self count` additions of the bump) and the
+// best n_common aids outside the session from otto_cand_lookup_self (inserted after every session aid, in most_common
+// order; weight = `count` additions of the bump to 0.0). most_common(n_pred) = rank by (weight desc, insertion asc),
+// every entry counts the entries ahead of it.
+constexpr int RP_THREADS = 256;
+constexpr int RP_MAXC = 64;
+struct RecPredArgs {
+    otto_recency_pred_params p;
+    const uint32_t* aid;
+    const uint8_t* type;
+    const int64_t* sess_off;
+    int64_t n_sess;
+    int32_t* pred;
+    double* weight;
+    int32_t* n_out;
+    uint32_t* err;
+};
+
+__global__ __launch_bounds__(RP_THREADS) void k_recency_pred(RecPredArgs a) {
+    constexpr int MAXL = OTTO_CAND_MAX_SESSION;
+    __shared__ uint32_t s_aid[MAXL];
+    __shared__ uint8_t s_ty[MAXL];
+    __shared__ uint8_t s_first[MAXL];
+    __shared__ double s_wc[MAXL];                       // curve weight x type coefficient of event i (current target)
+    __shared__ double s_w[MAXL + RP_MAXC];              // final weight of entry e: first occurrence at e, or candidate MAXL + r
+    __shared__ uint8_t s_live[MAXL + RP_MAXC];
+    __shared__ uint32_t s_nu;
+    const int tid = threadIdx.x;
+    const int NT = a.p.n_targets, NC = a.p.n_common, NP = a.p.n_pred;
+    for (int64_t s = blockIdx.x; s < a.n_sess; s += gridDim.x) {
+        const int64_t lo = a.sess_off[s], hi = a.sess_off[s + 1];
+        const int n = (int)(hi - lo);
+        if (n > MAXL) {
+            if (tid == 0) atomicAdd(a.err, 1u);
+            continue;
+        }
+        if (tid == 0) s_nu = 0;
+        for (int i = tid; i < n; i += RP_THREADS) { s_aid[i] = a.aid[lo + i]; s_ty[i] = a.type[lo + i]; }
+        __syncthreads();
+        for (int i = tid; i < n; i += RP_THREADS) {
+            const uint32_t ai = s_aid[i];
+            bool first = true;
+            for (int j = 0; j < i; ++j) first = first && s_aid[j] != ai;
+            s_first[i] = first ? 1 : 0;
+            if (first) atomicAdd(&s_nu, 1u);
+        }
+        __syncthreads();
+        const int nu = (int)s_nu;
+        if (nu < a.p.min_unique) {
+            if (tid < NT) a.n_out[(size_t)tid * a.n_sess + s] = -1;
+            for (int t = 0; t < NT; ++t)
+                for (int q = tid; q < NP; q += RP_THREADS) {
+                    a.pred[((size_t)t * a.n_sess + s) * NP + q] = -1;
+                    if (a.weight) a.weight[((size_t)t * a.n_sess + s) * NP + q] = 0.0;
+                }
+            __syncthreads();
+            continue;
+        }
+        for (int t = 0; t < NT; ++t) {
+            const double start = a.p.start[t], stop = a.p.stop[t], bump = a.p.bump[t];
+            for (int i = tid; i < n; i += RP_THREADS) {
+                const uint32_t ty = s_ty[i];
+                const double coef = ty < 3u ? a.p.type_coef[ty] : 0.0;
+                double y = start;
+                if (n > 1) {
+                    const double step = __ddiv_rn(__dsub_rn(stop, start), (double)(n - 1));
+                    y = i == n - 1 ? stop : __dadd_rn(__dmul_rn((double)i, step), start);
+                }
+                s_wc[i] = __dmul_rn(__dsub_rn(exp2(y), 1.0), coef);
+            }
+            for (int e = tid; e < MAXL + RP_MAXC; e += RP_THREADS) s_live[e] = 0;
+            __syncthreads();
+            const int ncand = min(min(a.p.d_n_cand[t][s], NC), RP_MAXC);
+            for (int e = tid; e < MAXL + RP_MAXC; e += RP_THREADS) {
+                double w = 0.0;
+                int reps = 0;
+                bool live = false;
+                if (e < n) {
+                    if (s_first[e]) {
+                        const uint32_t ai = s_aid[e];
+                        for (int j = e; j < n; ++j)
+                            if (s_aid[j] == ai) w = __dadd_rn(w, s_wc[j]);
+                        reps = a.p.d_self_count[t][lo + e];
+                        live = true;
+                    }
+                } else if (e >= MAXL && e - MAXL < ncand) {
+                    reps = a.p.d_count[t][(size_t)s * NC + (e - MAXL)];
+                    live = true;
+                }
+                for (int r = 0; r < reps; ++r) w = __dadd_rn(w, bump);
+                if (live) { s_w[e] = w; s_live[e] = 1; }
+            }
+            __syncthreads();
+            const size_t ob = ((size_t)t * a.n_sess + s) * NP;
+            for (int e = tid; e < MAXL + RP_MAXC; e += RP_THREADS) {
+                if (!s_live[e]) continue;
+                const double we = s_w[e];
+                int rank = 0;
+                for (int r = 0; r < n; ++r)
+                    if (s_live[r] && (s_w[r] > we || (s_w[r] == we && r < e))) ++rank;
+                for (int r = MAXL; r < MAXL + ncand; ++r)
+                    if (s_w[r] > we || (s_w[r] == we && r < e)) ++rank;
+                if (rank < NP) {
+                    a.pred[ob + rank] = e < MAXL ? (int32_t)s_aid[e] : a.p.d_cand[t][(size_t)s * NC + (e - MAXL)];
+                    if (a.weight) a.weight[ob + rank] = we;
+                }
+            }
+            const int total = nu + ncand;
+            for (int q = total + tid; q < NP; q += RP_THREADS) {
+                a.pred[ob + q] = -1;
+                if (a.weight) a.weight[ob + q] = 0.0;
+            }
+            if (tid == 0) a.n_out[(size_t)t * a.n_sess + s] = total < NP ? total : NP;
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace otto
 
 using namespace otto;
@@ -469,8 +621,8 @@ extern "C" int otto_recency_candidates(const otto_recency_params* p, const uint3
 }
 
 
-extern "C" int otto_cand_lookup(const otto_cand_params* p, const uint32_t* d_aid, const uint8_t* d_type, const int64_t* d_sess_off,
-                                int64_t n_sess, int32_t* d_cand, int32_t* d_count, int32_t* d_n, void* stream) {
+static int cand_lookup(const otto_cand_params* p, const uint32_t* d_aid, const uint8_t* d_type, const int64_t* d_sess_off,
+                       int64_t n_sess, int32_t* d_cand, int32_t* d_count, int32_t* d_n, int32_t* d_self, void* stream) {
     OTTO_REQUIRE(p && d_sess_off && d_cand && d_count && d_n, "otto_cand_lookup: null argument");
     OTTO_REQUIRE(p->n_aids > 0 && p->n_aids <= (1u << 26), "n_aids must be in [1, 2^26]");
     OTTO_REQUIRE(p->k >= 1 && p->k <= 32, "k must be in [1, 32]");
@@ -481,7 +633,7 @@ extern "C" int otto_cand_lookup(const otto_cand_params* p, const uint32_t* d_aid
     for (int m = 0; m < p->n_matrices; ++m) OTTO_REQUIRE(p->d_mat_y[m] && p->d_mat_n[m], "matrix %d is null", m);
     for (int t = 0; t < p->n_terms; ++t) {
         OTTO_REQUIRE(p->term_matrix[t] >= 0 && p->term_matrix[t] < p->n_matrices, "term %d: bad matrix", t);
-        OTTO_REQUIRE(p->term_source[t] >= 0 && p->term_source[t] <= OTTO_CAND_SRC_LAST, "term %d: bad source", t);
+        OTTO_REQUIRE(p->term_source[t] >= 0 && p->term_source[t] <= OTTO_CAND_SRC_C, "term %d: bad source", t);
     }
     if (n_sess <= 0) return 0;
     OTTO_REQUIRE(d_aid && d_type, "null event arrays");
@@ -493,7 +645,7 @@ extern "C" int otto_cand_lookup(const otto_cand_params* p, const uint32_t* d_aid
     memset(&a, 0, sizeof a);
     a.p = *p;
     a.aid = d_aid; a.type = d_type; a.sess_off = d_sess_off; a.n_sess = n_sess;
-    a.cand = d_cand; a.count = d_count; a.n_out = d_n; a.err = d_err;
+    a.cand = d_cand; a.count = d_count; a.n_out = d_n; a.err = d_err; a.self_count = d_self;
     // short sessions first (most of them), then the long ones; each variant skips the other's sessions
     a.lo_len = 0; a.hi_len = CD_SMALL_MAXL;
     const int grid_s = (int)(n_sess < 256 * 10 ? n_sess : 256 * 10);
@@ -508,6 +660,47 @@ extern "C" int otto_cand_lookup(const otto_cand_params* p, const uint32_t* d_aid
     (void)hipFree(d_err);
     OTTO_REQUIRE(le == hipSuccess && ce == hipSuccess && se == hipSuccess, "k_cand failed: %s", hipGetErrorString(le != hipSuccess ? le : (ce != hipSuccess ? ce : se)));
     OTTO_REQUIRE(err == 0, "%u session(s) longer than %d events", err, OTTO_CAND_MAX_SESSION);
+    return 0;
+}
+
+extern "C" int otto_cand_lookup(const otto_cand_params* p, const uint32_t* d_aid, const uint8_t* d_type, const int64_t* d_sess_off,
+                                int64_t n_sess, int32_t* d_cand, int32_t* d_count, int32_t* d_n, void* stream) {
+    return cand_lookup(p, d_aid, d_type, d_sess_off, n_sess, d_cand, d_count, d_n, nullptr, stream);
+}
+
+extern "C" int otto_cand_lookup_self(const otto_cand_params* p, const uint32_t* d_aid, const uint8_t* d_type, const int64_t* d_sess_off,
+                                     int64_t n_sess, int32_t* d_cand, int32_t* d_count, int32_t* d_n, int32_t* d_self_count,
+                                     void* stream) {
+    OTTO_REQUIRE(d_self_count, "otto_cand_lookup_self: null d_self_count");
+    return cand_lookup(p, d_aid, d_type, d_sess_off, n_sess, d_cand, d_count, d_n, d_self_count, stream);
+}
+
+extern "C" int otto_recency_predictions(const otto_recency_pred_params* p, const uint32_t* d_aid, const uint8_t* d_type,
+                                        const int64_t* d_sess_off, int64_t n_sess, int32_t* d_pred, double* d_weight, int32_t* d_n,
+                                        void* stream) {
+    OTTO_REQUIRE(p && d_sess_off && d_pred && d_n, "otto_recency_predictions: null argument");
+    OTTO_REQUIRE(p->n_targets >= 1 && p->n_targets <= OTTO_RECENCY_MAX_TARGETS, "n_targets must be in [1, %d]", OTTO_RECENCY_MAX_TARGETS);
+    OTTO_REQUIRE(p->n_pred >= 1 && p->n_pred <= 64 && p->n_common >= 1 && p->n_common <= RP_MAXC, "n_pred in [1, 64], n_common in [1, %d]", RP_MAXC);
+    for (int t = 0; t < p->n_targets; ++t)
+        OTTO_REQUIRE(p->d_cand[t] && p->d_count[t] && p->d_n_cand[t] && p->d_self_count[t], "target %d: null input", t);
+    if (n_sess <= 0) return 0;
+    OTTO_REQUIRE(d_aid && d_type, "null event arrays");
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t* d_err = nullptr;
+    OTTO_HIP(hipMalloc(&d_err, 4));
+    OTTO_HIP(hipMemsetAsync(d_err, 0, 4, s));
+    RecPredArgs a;
+    memset(&a, 0, sizeof a);
+    a.p = *p; a.aid = d_aid; a.type = d_type; a.sess_off = d_sess_off; a.n_sess = n_sess;
+    a.pred = d_pred; a.weight = d_weight; a.n_out = d_n; a.err = d_err;
+    k_recency_pred<<<(int)(n_sess < 256 * 8 ? n_sess : 256 * 8), RP_THREADS, 0, s>>>(a);
+    hipError_t le = hipGetLastError();
+    uint32_t h_err = 0;
+    if (le == hipSuccess) le = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, s);
+    if (le == hipSuccess) le = hipStreamSynchronize(s);
+    (void)hipFree(d_err);
+    if (le != hipSuccess) { set_error("otto_recency_predictions: %s", hipGetErrorString(le)); return -5; }
+    OTTO_REQUIRE(h_err == 0, "%u session(s) longer than %d events", h_err, OTTO_CAND_MAX_SESSION);
     return 0;
 }
 
