@@ -1097,7 +1097,7 @@ __device__ __forceinline__ void for_each_record_batch(const uint64_t* sorted_des
 // the segments of a wave's 64 runs are numbered by a wave scan and dealt to the eight 8-lane groups, so a wave-instruction
 // carries up to 64 records whatever the run lengths are (two 32-lane runs per instruction fill ~40 % of the lanes at the
 // OTTO run-length mix; the consumer's insert rounds -- its cost -- scale with the instructions, not the records).
-// s_seg: 256 bytes of LDS private to the wave (segment -> lane that holds the run's descriptor).
+// s_seg: 256 bytes of LDS private to the wave (segment -> lane that holds the run's descriptor | segment number << 6).
 // NEED_SL: the consumer wants the record's slot (time channel lookup); otherwise the slot arrays are not kept
 template <int NW, int GATHER_U, bool NEED_SL, typename FB>
 __device__ __forceinline__ void for_each_record_seg(const uint64_t* sorted_desc, const uint32_t* rec, uint64_t r0, uint64_t r1,
@@ -1119,7 +1119,7 @@ __device__ __forceinline__ void for_each_record_seg(const uint64_t* sorted_desc,
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k)
-            if (k < segs) s_seg[excl + k] = (uint8_t)lane;
+            if (k < segs) s_seg[excl + k] = (uint8_t)(lane | (k << 6));      // descriptor lane | segment of the run (len <= 32: 4 segments)
         wave_lds_sync();
         const int nstep = (int)((total + 7u) >> 3);
         uint32_t rcA[GATHER_U], rcB[GATHER_U];
@@ -1130,10 +1130,9 @@ __device__ __forceinline__ void for_each_record_seg(const uint64_t* sorted_desc,
             for (int u = 0; u < GATHER_U; ++u) {
                 const uint32_t q = (uint32_t)(t + u) * 8u + g;
                 const bool has = q < total;
-                const int r = has ? (int)s_seg[q] : 0;
-                const uint64_t dd = (uint64_t)__shfl((unsigned long long)d, r, 64);
-                const uint32_t ex = (uint32_t)__shfl((int)excl, r, 64);
-                const uint32_t off = (q - ex) * 8u + gl;
+                const uint32_t r = has ? (uint32_t)s_seg[q] : 0u;
+                const uint64_t dd = (uint64_t)__shfl((unsigned long long)d, (int)(r & 63u), 64);
+                const uint32_t off = (r >> 6) * 8u + gl;
                 const uint64_t slot = (dd >> 8) + off;
                 if (NEED_SL) sl[NEED_SL ? u : 0] = slot;
                 ok[u] = has && off < (uint32_t)(dd & 0xFFull);
@@ -1744,8 +1743,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         auto packed_add = [&](uint32_t rc) -> unsigned long long {
             uint32_t add0, add1, add2;
             if (GROUP == OTTO_COVIS_GROUP_TYPE) {
-                const uint32_t tyj = (rc >> REC_AID_BITS) & 3u;
-                add0 = tyj == 0; add1 = tyj == 1; add2 = tyj == 2;
+                const uint32_t tyj = (rc >> REC_AID_BITS) & 3u;              // counter tyj: bit 12 * tyj (type 3 does not occur: 36 & 31 = 4 is masked off)
+                return (unsigned long long)((1u << ((tyj * 12u) & 31u)) & 0x01001001u);
             } else {
                 const uint32_t fb = (rc >> 28) >> a.chan_shift;
                 add0 = fb & 1u; add1 = (fb >> 1) & 1u; add2 = (fb >> 2) & 1u;
@@ -1777,17 +1776,19 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 if (__ballot(any) == 0) continue;
                 if (PACKED) {
                     uint32_t oldhi[CH];                       // high word of the slot before the CAS: 0xFFFFFFFF = was empty
+                    unsigned long long addq[CH];              // the record's counter increment, built once
 #pragma unroll
                     for (int q = 0; q < CH; ++q) {
                         const uint32_t r = rc[c0 + q < N ? c0 + q : 0];
+                        const uint32_t slot = rec_hash(r) >> (32 - LOG2T);
                         oldhi[q] = 0xFFFFFFFFu;
+                        addq[q] = packed_add(r);
                         if (ok[q]) {
-                            const unsigned long long o = atomicCAS((unsigned long long*)&s_tab[PACKED ? rec_hash(r) >> (32 - LOG2T) : 0],
-                                                                   (unsigned long long)TAB_EMPTY,
-                                                                   ((unsigned long long)(r & REC_AID_MASK) << 36) | packed_add(r));
+                            const unsigned long long o = atomicCAS((unsigned long long*)&s_tab[PACKED ? slot : 0], (unsigned long long)TAB_EMPTY,
+                                                                   ((unsigned long long)(r & REC_AID_MASK) << 36) | addq[q]);
                             oldhi[q] = (uint32_t)(o >> 32);
                         }
-                        note_new(ok[q] && oldhi[q] == 0xFFFFFFFFu, rec_hash(r) >> (32 - LOG2T));
+                        note_new(ok[q] && oldhi[q] == 0xFFFFFFFFu, slot);
                     }
 #pragma unroll
                     for (int q = 0; q < CH; ++q) {
@@ -1796,8 +1797,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                         const uint32_t y = r & REC_AID_MASK, slot = rec_hash(r) >> (32 - LOG2T);
                         uint32_t late = 0xFFFFFFFFu;
                         if (oldhi[q] != 0xFFFFFFFFu) {
-                            if ((oldhi[q] >> 4) == y) atomicAdd((unsigned long long*)&s_tab[PACKED ? slot : 0], packed_add(r));
-                            else late = probe_on(y, slot, packed_add(r), (unsigned long long)y << 36);
+                            if ((oldhi[q] >> 4) == y) atomicAdd((unsigned long long*)&s_tab[PACKED ? slot : 0], addq[q]);
+                            else late = probe_on(y, slot, addq[q], (unsigned long long)y << 36);
                         }
                         note_new(late != 0xFFFFFFFFu, late);
                     }
@@ -1850,7 +1851,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 uint64_t uw = 0, qw = 0;
                 if (y != KEY_EMPTY) {
                     if (GROUP == OTTO_COVIS_GROUP_TIME) qw = 65536ull * v0 + (((uint64_t)v2 << 32) | v1);
-                    else if (PACKED) uw = v0 * a.coef[j][0] + v1 * a.coef[j][1] + v2 * a.coef[j][2];   // 12-bit counts x 8-bit weights: 32-bit math
+                    else if (PACKED) uw = __umul24(v0, a.coef[j][0]) + __umul24(v1, a.coef[j][1]) + __umul24(v2, a.coef[j][2]);   // 12-bit counts x 8-bit weights: v_mad_u32_u24 (v_mul_lo_u32 is quarter rate)
                     else uw = (uint64_t)v0 * a.coef[j][0] + (uint64_t)v1 * a.coef[j][1] + (uint64_t)v2 * a.coef[j][2];
                 }
                 kmake(out[j], uw, qw, y);
@@ -1948,7 +1949,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 }
             };
             auto weight = [&](uint32_t v0, uint32_t v1, uint32_t v2, uint32_t c0, uint32_t c1, uint32_t c2) -> uint64_t {
-                if (PACKED) return (uint64_t)(v0 * c0 + v1 * c1 + v2 * c2);      // 12-bit counts x 8-bit weights: 32-bit math
+                if (PACKED) return (uint64_t)(__umul24(v0, c0) + __umul24(v1, c1) + __umul24(v2, c2));      // 12-bit counts x 8-bit weights: v_mad_u32_u24
                 return (uint64_t)v0 * c0 + (uint64_t)v1 * c1 + (uint64_t)v2 * c2;
             };
             auto slot_lohi = [&](int i, K& kl, K& kh) {
@@ -2262,7 +2263,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 uint64_t uw = 0, qw = 0;
                 if (y != KEY_EMPTY) {
                     if (GROUP == OTTO_COVIS_GROUP_TIME) qw = 65536ull * v0 + (((uint64_t)v2 << 32) | v1);
-                    else if (PACKED) uw = v0 * c0 + v1 * c1 + v2 * c2;
+                    else if (PACKED) uw = __umul24(v0, c0) + __umul24(v1, c1) + __umul24(v2, c2);
                     else uw = (uint64_t)v0 * c0 + (uint64_t)v1 * c1 + (uint64_t)v2 * c2;
                 }
                 K r;
