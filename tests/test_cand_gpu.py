@@ -196,8 +196,7 @@ def test_recency_branch_predictions_with_neighbour_and_list_bumps(gpu_device):
             if len(set(ev.aid[lo:hi].tolist())) < min_unique:
                 assert (n[:, s] == -1).all() and (pred[:, s] == -1).all()
                 continue
-            want = ro.session_recency_predictions(ev.aid[lo:hi], ev.type[lo:hi], top['time_weighted'], top['cart_weighted'],
-                                                  top['cart_order'], nbd)
+            want = ro.session_recency_predictions(ev.aid[lo:hi], ev.type[lo:hi], top, nbd)
             for t, (wa, ww) in enumerate(want):
                 assert n[t, s] == len(wa), (s, t, n[t, s], len(wa))
                 got, gw = pred[t, s, :n[t, s]].tolist(), w[t, s, :n[t, s]]
