@@ -195,8 +195,9 @@ def test_streamed_host_ingest_equals_device_feed(gpu_device):
             assert np.array_equal(g, w), kind
 
 
-def _dp_worker(rank, world, port, q, root):
-    """One rank of the data-parallel MF test: both ranks share cuda:0 (the box has one GPU), gloo carries the collectives."""
+def _dp_worker(rank, world, port, q, root, backend='gloo', rows_per_launch=4096, epochs=40):
+    """One rank of the data-parallel MF test: the ranks share cuda:0 (the box has one GPU); gloo carries the collectives of
+    the 2-rank run, nccl (= RCCL) those of the world-of-one run."""
     import os
     import sys
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -205,7 +206,7 @@ def _dp_worker(rank, world, port, q, root):
     import torch
     import torch.distributed as dist
     from otto_amd.matrix_factorization.bpr import BPR, ItemTableSync, train_epoch, full_sort_topk_sharded
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device('cuda:0')
     torch.cuda.set_device(dev)
     u, i, held, n_users, n_items, d = _planted(128)
@@ -221,8 +222,8 @@ def _dp_worker(rank, world, port, q, root):
     du, di = torch.from_numpy(u[mine]).to(dev), torch.from_numpy(i[mine]).to(dev)
     row0 = int(np.flatnonzero(mine)[0])
     sync = ItemTableSync(model.item_embedding.weight.data)
-    losses = [train_epoch(model, du, di, lr=0.2, seed=1, epoch=e, rows_per_launch=4096, row0=row0, sync=sync, sync_every=2)
-              for e in range(40)]
+    losses = [train_epoch(model, du, di, lr=0.2, seed=1, epoch=e, rows_per_launch=rows_per_launch, row0=row0, sync=sync, sync_every=2)
+              for e in range(epochs)]
     V = model.item_embedding.weight.data
     # user rows are rank-private: gather them so every rank can score all users
     U = model.user_embedding.weight.data
@@ -312,6 +313,53 @@ def test_data_parallel_bpr_two_ranks_and_sharded_scoring(gpu_device):
     for got_i, got_s in ((idu, scu), (idi, sci)):
         assert np.array_equal(got_i, id1) and np.array_equal(got_s, sc1), 'sharded scoring differs from the unsharded call'
     assert np.array_equal(res[1][6], idi) and np.array_equal(res[1][4], idu)      # every rank holds the full result
+
+
+def test_data_parallel_bpr_over_rccl_world_of_one(gpu_device):
+    """The same data-parallel code over the real RCCL backend (world of one process, as the covisitation exchange is tested):
+    ItemTableSync's asynchronous dense all-reduce on device tensors and, with launches small enough to be tracked, its
+    sparse (row id, delta row) all-gather; both sharded scorings (all-reduce MAX of int32 / float32, all-gather + device
+    merge). With one rank the exchange adds nothing, so training must land where the plain loop lands (hogwild: loosely)
+    and the sharded scorings must equal the unsharded call exactly."""
+    import queue
+    import socket
+    import torch.multiprocessing as mp
+    from conftest import ROOT
+    from otto_amd.matrix_factorization.bpr import BPR, train_epoch
+    u, i, held, n_users, n_items, d = _planted(128)
+    torch.manual_seed(0)
+    ref = BPR(n_users, n_items, d)
+    with torch.no_grad():
+        ref.user_embedding.weight.normal_(0, 0.1)
+        ref.item_embedding.weight.normal_(0, 0.1)
+    ref.to(gpu_device)
+    du, di = torch.from_numpy(u).to(gpu_device), torch.from_numpy(i).to(gpu_device)
+    for rows, epochs, want_stat in ((4096, 6, 'dense'), (32, 2, 'sparse')):    # 2 launches of 32 rows touch < 1/8 of the items
+        ref_losses = [train_epoch(ref, du, di, lr=0.2, seed=1, epoch=e, rows_per_launch=rows) for e in range(epochs)]
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        p = ctx.Process(target=_dp_worker, args=(0, 1, port, q, ROOT, 'nccl', rows, epochs))
+        p.start()
+        res = None
+        for _ in range(300):
+            try:
+                res = q.get(timeout=1)
+                break
+            except queue.Empty:
+                if not p.is_alive():
+                    break
+        p.join(60)
+        assert res is not None and p.exitcode == 0, f'RCCL worker failed (exit code {p.exitcode})'
+        _, V, losses, id1, sc1, idu, scu, idi, sci, stats = res
+        assert stats[want_stat] > 0, stats
+        assert np.isfinite(V).all() and losses[-1] < losses[0]
+        if rows == 4096:          # same launches as the first reference run from the same initial tables
+            assert losses[-1] == pytest.approx(ref_losses[-1], rel=0.1)
+        for got_i, got_s in ((idu, scu), (idi, sci)):
+            assert np.array_equal(got_i, id1) and np.array_equal(got_s, sc1), 'sharded scoring differs from the unsharded call'
 
 
 @pytest.mark.parametrize('variant', ['ms-uint64-strings', 'seconds-codes', 'arrow-table', 'datetime'])
