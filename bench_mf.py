@@ -3,8 +3,9 @@ mode) on the OTTO-shape (session, aid) stream, plus the reference-config R-MF (S
 scoring rate.
 
 N > 1: every rank owns the rows of its own session chunk (user rows are rank-private), the item table is replicated and
-the rows it touched are exchanged every ``SYNC_EVERY`` launches (``bpr.ItemTableSync``: sparse (row id, delta row)
-all-gather over RCCL). ``--scaling weak``: ``--mf-rows`` rows per rank; ``strong``: ``--mf-rows`` rows split over the ranks."""
+synchronised every ``SYNC_EVERY`` launches by ``bpr.ItemTableSync`` over RCCL (launches of 16.7 M rows touch nearly every
+item row: asynchronous dense all-reduce of the delta table, folded in one period later; small launches: sparse (row id,
+delta row) all-gather). ``--scaling weak``: ``--mf-rows`` rows per rank; ``strong``: ``--mf-rows`` rows split over the ranks."""
 import time
 
 import numpy as np
@@ -51,7 +52,8 @@ def run(a, dev, rank, world, cpu_baseline_fn=None, traffic_fn=None):
             if timed:
                 ev1[q].record()
             if world > 1:
-                sync.touched(items[lo:hi])
+                if hi - lo <= n_items // 4:          # few rows: worth tracking them for the sparse exchange (as bpr.train_epoch does)
+                    sync.touched(items[lo:hi])
                 if (q + 1) % SYNC_EVERY == 0 or q == n_launch - 1:
                     sync.exchange()
 
@@ -88,7 +90,7 @@ def run(a, dev, rank, world, cpu_baseline_fn=None, traffic_fn=None):
         'config': {'workload': f'BPR-MF hogwild SGD, {n_users} sessions x {n_items} aids x {d}-d fp32, {rows} (session, aid) rows per GPU '
                                f'in random order, uniform negatives from the counter RNG, launches of {ROWS_PER_LAUNCH}',
                    'rows_per_gpu': rows, 'factors': d,
-                   'parallelism': 'single GPU' if world == 1 else f'data-parallel x{world} ({a.scaling} scaling): user rows private, touched item rows exchanged as sparse (id, delta row) all-gather (RCCL) every {SYNC_EVERY} launches'},
+                   'parallelism': 'single GPU' if world == 1 else f'data-parallel x{world} ({a.scaling} scaling): user rows private, item table synchronised every {SYNC_EVERY} launches by ItemTableSync (RCCL; exchanges this run: {dict(sync.stats) if sync is not None else {}}; dense = asynchronous all-reduce of the delta table folded in one period later, sparse = (id, delta row) all-gather)'},
         'roofline': {'kernel': 'k_bpr_hogwild', 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(gbs / HBM_PEAK_GBS, 4),
                      'traffic': traffic_fn(('k_bpr_hogwild',)) if (traffic_fn and d == 64 and rows >= ROWS_PER_LAUNCH) else None,
