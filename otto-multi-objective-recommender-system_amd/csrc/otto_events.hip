@@ -94,15 +94,23 @@ struct CountAt {
     __device__ uint64_t operator()(int64_t i) const { return c[i]; }
 };
 
+// Scatter of one pass. Ranks: stable in-wave rank of a key among the wave's keys of the same digit (8 ballots), per-wave digit
+// counters in LDS. The tile is then REORDERED IN LDS by digit and written out in that order: consecutive lanes hold
+// consecutive positions of a digit run, so a wave-instruction touches a handful of cache lines instead of up to 64 (the
+// direct form -- every lane storing its key at base[digit] + rank -- ran at ~1.5 TB/s of traffic).
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* key, const uint32_t* idx, int64_t n, int shift, int64_t nb,
                                                            const uint64_t* offs, uint64_t* key_out, uint32_t* idx_out) {
-    __shared__ uint32_t s_wcnt[RS_WAVES][256];
-    __shared__ uint64_t s_wbase[RS_WAVES][256];
+    __shared__ uint32_t s_wcnt[RS_WAVES][256];      // per wave: keys of digit d, then the wave's first position of d in the tile
+    __shared__ uint32_t s_scan[RS_THREADS / 64 + 1];
+    __shared__ long long s_delta[256];              // global position of digit d's run minus its position in the tile
+    __shared__ uint64_t s_k[RS_TILE];
+    __shared__ uint32_t s_i[RS_TILE];
     const int w = threadIdx.x >> 6;
     const unsigned lane = lane_id();
     for (int q = 0; q < RS_WAVES; ++q) s_wcnt[q][threadIdx.x] = 0;
     __syncthreads();
-    const int64_t wave_base = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * (RS_TILE / RS_WAVES);
+    const int64_t tile_base = (int64_t)blockIdx.x * RS_TILE;
+    const int64_t wave_base = tile_base + (int64_t)w * (RS_TILE / RS_WAVES);
     uint64_t k[RS_ITEMS];
     uint32_t id[RS_ITEMS], lr[RS_ITEMS];
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -112,6 +120,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* key, 
         const bool valid = i < n;
         k[c] = valid ? key[i] : ~0ull;
         id[c] = valid ? idx[i] : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < RS_ITEMS; ++c) {
+        const bool valid = wave_base + (int64_t)c * 64 + lane < n;
         const uint32_t dig = (uint32_t)(k[c] >> shift) & 255u;
         uint64_t m = __ballot(valid);
 #pragma unroll
@@ -133,20 +145,36 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* key, 
     }
     __syncthreads();
     {
-        uint64_t run = offs[(int64_t)threadIdx.x * nb + blockIdx.x];
-        for (int q = 0; q < RS_WAVES; ++q) {
-            s_wbase[q][threadIdx.x] = run;
-            run += s_wcnt[q][threadIdx.x];
-        }
+        // digit threadIdx.x: position of its run in the tile (exclusive scan over the digits), every wave's share of it
+        uint32_t tot = 0, cnt[RS_WAVES];
+#pragma unroll
+        for (int q = 0; q < RS_WAVES; ++q) { cnt[q] = s_wcnt[q][threadIdx.x]; tot += cnt[q]; }
+        uint32_t all;
+        uint32_t run = block_excl_scan<uint32_t, RS_THREADS>(tot, s_scan, &all);
+        s_delta[threadIdx.x] = (long long)offs[(int64_t)threadIdx.x * nb + blockIdx.x] - (long long)run;
+#pragma unroll
+        for (int q = 0; q < RS_WAVES; ++q) { s_wcnt[q][threadIdx.x] = run; run += cnt[q]; }
     }
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < RS_ITEMS; ++c) {
-        const int64_t i = wave_base + (int64_t)c * 64 + lane;
-        if (i < n) {
-            const uint64_t d = s_wbase[w][(uint32_t)(k[c] >> shift) & 255u] + lr[c];
-            key_out[d] = k[c];
-            idx_out[d] = id[c];
+        if (wave_base + (int64_t)c * 64 + lane < n) {
+            const uint32_t p = s_wcnt[w][(uint32_t)(k[c] >> shift) & 255u] + lr[c];
+            s_k[p] = k[c];
+            s_i[p] = id[c];
+        }
+    }
+    __syncthreads();
+    const int64_t left = n - tile_base;
+    const uint32_t tile_n = left < (int64_t)RS_TILE ? (uint32_t)left : (uint32_t)RS_TILE;
+#pragma unroll
+    for (int c = 0; c < RS_ITEMS; ++c) {
+        const uint32_t p = (uint32_t)c * RS_THREADS + threadIdx.x;
+        if (p < tile_n) {
+            const uint64_t kk = s_k[p];
+            const long long g = s_delta[(uint32_t)(kk >> shift) & 255u] + (long long)p;
+            key_out[g] = kk;
+            idx_out[g] = s_i[p];
         }
     }
 }
