@@ -28,7 +28,9 @@ struct SortWs {          // carved from the caller's workspace
     unsigned long long* orand;   // [2]: OR and AND of all keys; [2]: error counter of the type map
 };
 
-static int64_t rs_blocks(int64_t n) { return (n + RS_TILE - 1) / RS_TILE; }
+constexpr int RS_SUB = 4;                            // tiles a workgroup takes one after the other (one counter row per workgroup)
+constexpr int64_t RS_SPAN = (int64_t)RS_TILE * RS_SUB;
+static int64_t rs_blocks(int64_t n) { return (n + RS_SPAN - 1) / RS_SPAN; }
 
 static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -79,11 +81,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t* key, int
     __shared__ uint32_t s_h[256];
     s_h[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    const int64_t base = (int64_t)blockIdx.x * RS_SPAN;
+    for (int sub = 0; sub < RS_SUB; ++sub) {
 #pragma unroll
-    for (int c = 0; c < RS_ITEMS; ++c) {
-        const int64_t i = base + (int64_t)c * RS_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&s_h[(key[i] >> shift) & 255u], 1u);
+        for (int c = 0; c < RS_ITEMS; ++c) {
+            const int64_t i = base + (int64_t)sub * RS_TILE + (int64_t)c * RS_THREADS + threadIdx.x;
+            if (i < n) atomicAdd(&s_h[(key[i] >> shift) & 255u], 1u);
+        }
     }
     __syncthreads();
     counts[(int64_t)threadIdx.x * nb + blockIdx.x] = s_h[threadIdx.x];
@@ -105,11 +109,15 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* key, 
     __shared__ long long s_delta[256];              // global position of digit d's run minus its position in the tile
     __shared__ uint64_t s_k[RS_TILE];
     __shared__ uint32_t s_i[RS_TILE];
+    __shared__ unsigned long long s_gbase[256];     // where the workgroup's next key of digit d goes
     const int w = threadIdx.x >> 6;
     const unsigned lane = lane_id();
+    s_gbase[threadIdx.x] = offs[(int64_t)threadIdx.x * nb + blockIdx.x];
+    for (int sub = 0; sub < RS_SUB; ++sub) {
+    const int64_t tile_base = (int64_t)blockIdx.x * RS_SPAN + (int64_t)sub * RS_TILE;
+    if (tile_base >= n) break;
     for (int q = 0; q < RS_WAVES; ++q) s_wcnt[q][threadIdx.x] = 0;
     __syncthreads();
-    const int64_t tile_base = (int64_t)blockIdx.x * RS_TILE;
     const int64_t wave_base = tile_base + (int64_t)w * (RS_TILE / RS_WAVES);
     uint64_t k[RS_ITEMS];
     uint32_t id[RS_ITEMS], lr[RS_ITEMS];
@@ -151,7 +159,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* key, 
         for (int q = 0; q < RS_WAVES; ++q) { cnt[q] = s_wcnt[q][threadIdx.x]; tot += cnt[q]; }
         uint32_t all;
         uint32_t run = block_excl_scan<uint32_t, RS_THREADS>(tot, s_scan, &all);
-        s_delta[threadIdx.x] = (long long)offs[(int64_t)threadIdx.x * nb + blockIdx.x] - (long long)run;
+        s_delta[threadIdx.x] = (long long)s_gbase[threadIdx.x] - (long long)run;
+        s_gbase[threadIdx.x] += tot;
 #pragma unroll
         for (int q = 0; q < RS_WAVES; ++q) { s_wcnt[q][threadIdx.x] = run; run += cnt[q]; }
     }
@@ -176,6 +185,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* key, 
             key_out[g] = kk;
             idx_out[g] = s_i[p];
         }
+    }
+    __syncthreads();                                 // the next tile reuses the staging arrays
     }
 }
 
