@@ -104,15 +104,14 @@ struct CountAt {
 // direct form -- every lane storing its key at base[digit] + rank -- ran at ~1.5 TB/s of traffic).
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* key, const uint32_t* idx, int64_t n, int shift, int64_t nb,
                                                            const uint64_t* offs, uint64_t* key_out, uint32_t* idx_out) {
-    __shared__ uint32_t s_wcnt[RS_WAVES][256];      // per wave: keys of digit d, then the wave's first position of d in the tile
+    __shared__ uint16_t s_wcnt[RS_WAVES][256];      // per wave: keys of digit d, then the wave's first position of d in the tile (< 4096)
     __shared__ uint32_t s_scan[RS_THREADS / 64 + 1];
     __shared__ long long s_delta[256];              // global position of digit d's run minus its position in the tile
     __shared__ uint64_t s_k[RS_TILE];
     __shared__ uint32_t s_i[RS_TILE];
-    __shared__ unsigned long long s_gbase[256];     // where the workgroup's next key of digit d goes
     const int w = threadIdx.x >> 6;
     const unsigned lane = lane_id();
-    s_gbase[threadIdx.x] = offs[(int64_t)threadIdx.x * nb + blockIdx.x];
+    unsigned long long gbase = offs[(int64_t)threadIdx.x * nb + blockIdx.x];     // thread d: where the workgroup's next key of digit d goes
     for (int sub = 0; sub < RS_SUB; ++sub) {
     const int64_t tile_base = (int64_t)blockIdx.x * RS_SPAN + (int64_t)sub * RS_TILE;
     if (tile_base >= n) break;
@@ -144,7 +143,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* key, 
         uint32_t prev = 0;
         if (valid && (int)lane == leader) {
             prev = s_wcnt[w][dig];
-            s_wcnt[w][dig] = prev + (uint32_t)__popcll(m);
+            s_wcnt[w][dig] = (uint16_t)(prev + (uint32_t)__popcll(m));
         }
         prev = (uint32_t)__shfl((int)prev, leader, 64);
         lr[c] = prev + (uint32_t)__popcll(m & lt);
@@ -159,10 +158,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t* key, 
         for (int q = 0; q < RS_WAVES; ++q) { cnt[q] = s_wcnt[q][threadIdx.x]; tot += cnt[q]; }
         uint32_t all;
         uint32_t run = block_excl_scan<uint32_t, RS_THREADS>(tot, s_scan, &all);
-        s_delta[threadIdx.x] = (long long)s_gbase[threadIdx.x] - (long long)run;
-        s_gbase[threadIdx.x] += tot;
+        s_delta[threadIdx.x] = (long long)gbase - (long long)run;
+        gbase += tot;
 #pragma unroll
-        for (int q = 0; q < RS_WAVES; ++q) { s_wcnt[q][threadIdx.x] = run; run += cnt[q]; }
+        for (int q = 0; q < RS_WAVES; ++q) { s_wcnt[q][threadIdx.x] = (uint16_t)run; run += cnt[q]; }
     }
     __syncthreads();
 #pragma unroll
