@@ -52,7 +52,7 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
     __shared__ uint32_t s_aid[CD_MAXL];
     __shared__ uint8_t s_ty[CD_MAXL];
     __shared__ uint8_t s_flag[CD_MAXL];               // bit0 last occurrence, bit1 first click/cart, bit2 first cart/order, bit3 first click
-    __shared__ uint16_t s_src[5][CD_MAXL];            // U, CC, CO, LAST (the last event: a single source), C -- as EVENT positions
+    __shared__ uint16_t s_src[4][CD_MAXL];            // U, CC, CO, C -- as EVENT positions; source LAST is the last event itself
                                                       // (the aid is s_aid[position]; 16-bit entries keep two of the long-session workgroups on a CU)
     __shared__ uint32_t s_nsrc[5];
     __shared__ uint32_t s_base[CD_MAXQ];               // position of list q in the concatenation | len << 24
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
         // ---- A ----------------------------------------------------------------------------------------
         for (int i = tid; i < n; i += CD_THREADS) { s_aid[i] = a.aid[lo + i]; s_ty[i] = a.type[lo + i]; }
         if (tid < 3 || tid == 4) s_nsrc[tid] = 0;
-        if (tid == 3) { s_nsrc[3] = n > 0 ? 1u : 0u; s_src[3][0] = (uint16_t)(n > 0 ? n - 1 : 0); }
+        if (tid == 3) s_nsrc[3] = n > 0 ? 1u : 0u;
         if (a.self_count)
             for (int i = tid; i < n; i += CD_THREADS) a.self_count[lo + i] = 0;
         for (int i = tid; i < NC; i += CD_THREADS) s_sel[i] = 0;
@@ -111,9 +111,13 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
             if (fl & 1u) { s_src[0][ru] = (uint16_t)i; atomicAdd(&s_nsrc[0], 1u); }
             if (fl & 2u) { s_src[1][rcc] = (uint16_t)i; atomicAdd(&s_nsrc[1], 1u); }
             if (fl & 4u) { s_src[2][rco] = (uint16_t)i; atomicAdd(&s_nsrc[2], 1u); }
-            if (fl & 8u) { s_src[4][rc] = (uint16_t)i; atomicAdd(&s_nsrc[4], 1u); }
+            if (fl & 8u) { s_src[3][rc] = (uint16_t)i; atomicAdd(&s_nsrc[4], 1u); }
         }
         __syncthreads();
+        // aid of entry j of source list `src` (OTTO_CAND_SRC_*)
+        auto src_aid = [&](int src, uint32_t j) -> uint32_t {
+            return s_aid[src == OTTO_CAND_SRC_LAST ? (uint32_t)(n - 1) : (uint32_t)s_src[src == OTTO_CAND_SRC_C ? 3 : src][j]];
+        };
         // ---- B ----------------------------------------------------------------------------------------
         uint32_t tstart[OTTO_CAND_MAX_TERMS + 1];
         tstart[0] = 0;
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
                 int t = 0;
 #pragma unroll
                 for (int u = 1; u < OTTO_CAND_MAX_TERMS; ++u) t += (q >= tstart[u]) ? 1 : 0;
-                const uint32_t x = s_aid[s_src[a.p.term_source[t]][q - tstart[t]]];
+                const uint32_t x = src_aid(a.p.term_source[t], q - tstart[t]);
                 const int m = a.p.term_matrix[t];
                 const int Km = a.p.mat_k[m] > 0 ? a.p.mat_k[m] : K;
                 const int32_t ln = x < a.p.n_aids ? a.p.d_mat_n[m][x] : 0;
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
                     int t = 0;
 #pragma unroll
                     for (int u = 1; u < OTTO_CAND_MAX_TERMS; ++u) t += (q >= tstart[u]) ? 1 : 0;
-                    const uint32_t x = s_aid[s_src[a.p.term_source[t]][q - tstart[t]]];
+                    const uint32_t x = src_aid(a.p.term_source[t], q - tstart[t]);
                     const int m = a.p.term_matrix[t];
                     const uint32_t y = (uint32_t)a.p.d_mat_y[m][(size_t)x * (a.p.mat_k[m] > 0 ? a.p.mat_k[m] : K) + l2];
                     const uint32_t h = y * 0x9E3779B1u;
