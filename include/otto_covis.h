@@ -118,7 +118,8 @@ int otto_covis_stats(otto_covis_ctx* ctx, int64_t* out /* [OTTO_COVIS_STAT_COUNT
  *   "fused": 1 (default) fused in-order register pair-expand kernel when no filter kind is configured, 0 class-sorted kernels;
  *   "fast_path": 1 (default) gap-free window shortcut in the pair-expand kernels;
  *   "bucket_index": 1 (default) group the runs by aid_x with LDS atomics per 1024-aid bucket, 0 one global atomic per run;
- *   "packed_heavy": 1 (default) packed 12-bit-counter tables for heavy aids with fewer than 4096 runs;
+ *   "packed_heavy": packed 12-bit-counter tables for heavy aids with fewer than 4096 runs: 2 (default) 2^14 slots for aids that
+ *                   fit one table, 2^13-slot partitions beyond; 1: 2^14-slot partitions of twice the size; 0: wide tables only;
  *   "guess": 1 (default) single-pass top-k of a heavy aid's partitions from a sibling partition's threshold;
  *   "debug_skip": timing diagnostics only (results invalid): 1 no gather, 2 no top-k, 4 no table clear, 8 no inserts,
  *                 16 / 32 pair-expand without record stores / row loops. */

@@ -813,11 +813,17 @@ constexpr int L_LOG2T = 13, L_THREADS = 1024, L_CAP = 6144;
 constexpr int LP_LOG2T = 14;
 constexpr uint64_t PACKED_MAX_RUNS = 4096;
 // Layouts ("modes") of the heavy bin:  0: wide, 2^13 slots, partitions of l_cap records;
-//   1: packed, 2^14 slots, partitions of 2 * l_cap;  2: packed, 2^13 slots, the whole aid (n <= l_cap), 8 waves, two
-//   workgroups per CU. (Smaller tables for the small aids of the M bin were measured and did not pay.)
+//   1: packed, 2^14 slots, 16 waves, one workgroup per CU: aids of l_cap < n <= 2 * l_cap records as ONE item (no partition pass);
+//   2: packed, 2^13 slots, 8 waves, two workgroups per CU: the whole aid (n <= l_cap) or partitions of l_cap records
+//      (n > 2 * l_cap). Partitioned aids were in layout 1 with partitions of 2 * l_cap at first: half the items, but one
+//      workgroup per CU exposes every barrier, and with twice the partitions three of four items instead of one of two
+//      take the one-pass guess path (reduce L 12.5 -> 12.1 ms, partition 4.0 -> 3.7 ms; option packed_heavy = 1 is that rule).
+//   (Smaller tables for the small aids of the M bin were measured and did not pay.)
 __device__ __forceinline__ int heavy_mode(uint64_t c64, int allow_packed, uint32_t l_cap) {
     if (!allow_packed || (c64 >> CNT_REC_BITS) >= PACKED_MAX_RUNS) return 0;
-    return (c64 & CNT_REC_MASK) <= (uint64_t)l_cap ? 2 : 1;
+    const uint64_t n = c64 & CNT_REC_MASK;
+    if (allow_packed == 2) return (n <= (uint64_t)l_cap || n > 2ull * l_cap) ? 2 : 1;   // partitioned aids: 2^13 tables, partitions of l_cap
+    return n <= (uint64_t)l_cap ? 2 : 1;
 }
 __device__ __forceinline__ int heavy_log2t(uint64_t c64, int allow_packed, uint32_t l_cap) {
     return heavy_mode(c64, allow_packed, l_cap) == 1 ? LP_LOG2T : L_LOG2T;
@@ -2768,7 +2774,8 @@ struct otto_covis_ctx {
     int bucket_index = 1;          // option "bucket_index": LDS-atomic index build (0 = global-atomic histogram)
     DevBuf lorder[3][3], lrank, lmode_start;   // [bin][mode] processing order of the tiers / layouts (heavy: pilots first)
     uint64_t n_order[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    int packed_heavy = 1;          // option "packed_heavy": packed layout for heavy aids with < 4096 runs
+    int packed_heavy = 2;          // option "packed_heavy": packed layout for heavy aids with < 4096 runs (1: 2^14 tables for every aid
+                                   // above l_cap records, 2: 2^14 only for the aids that fit one table, 2^13 partitions of l_cap beyond)
     int items_allow_packed = -1;   // layout rule the L item list was built with (-1: not built)
     DevBuf tau_w, tau_y;           // threshold guesses of partitioned heavy aids (per reduce pass)
     int guess = 1;                 // option "guess": single-pass top-k from a sibling partition's threshold
@@ -3197,7 +3204,7 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
     a.n_work = a.n_items;
     if (a.n_items == 0) return 0;
     a.order = nullptr;
-    a.allow_packed = c->items_allow_packed > 0;
+    a.allow_packed = c->items_allow_packed > 0 ? c->items_allow_packed : 0;
     uint32_t* wc = c->counters.as<uint32_t>() + 1 + bin;
     OTTO_HIP(hipMemsetAsync(wc, 0, 4, s));
     a.work_counter = wc;
@@ -3346,7 +3353,7 @@ extern "C" int otto_covis_finalize(otto_covis_ctx* c, int group, int k, uint32_t
     hipStream_t s = (hipStream_t)stream;
     if (!c->index_valid) OTTO_TRY(build_index(c, s));
     // the time group has no packed layout: its heavy aids are partitioned for the wide table
-    const int want_packed = (group != OTTO_COVIS_GROUP_TIME && c->packed_heavy) ? 1 : 0;
+    const int want_packed = (group != OTTO_COVIS_GROUP_TIME && c->packed_heavy) ? c->packed_heavy : 0;
     if (c->items_allow_packed != want_packed) OTTO_TRY(build_items(c, 2, 0, s, want_packed));
     const uint32_t n_aids = p.n_aids;
     OTTO_HIP(hipMemsetAsync(d_out_n, 0, (size_t)n_kinds * n_aids * 4, s));
@@ -3430,7 +3437,7 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
         return 0;
     }
     if (strcmp(name, "debug_skip") == 0) { c->debug_skip = (int)value; return 0; }   // timing diagnostics, results invalid
-    if (strcmp(name, "packed_heavy") == 0) { c->packed_heavy = value != 0; c->index_valid = false; return 0; }
+    if (strcmp(name, "packed_heavy") == 0) { c->packed_heavy = value == 2 ? 2 : (value != 0); c->index_valid = false; return 0; }
     if (strcmp(name, "bucket_index") == 0) { c->bucket_index = value != 0; return 0; }
     if (strcmp(name, "guess") == 0) { c->guess = value != 0; return 0; }           // threshold guessing on/off (A/B)
     if (strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }           // fused in-order expansion on/off (A/B)
