@@ -1398,40 +1398,39 @@ __global__ __launch_bounds__(256) void k_aid_totals(const uint64_t* cnt64, const
 
 // All work lists of a build in ONE launch (replaces ten device-wide scans and seven fill launches): work items of the
 // three bins, the heavy bin's processing order per layout (pilots first), the partition-pass chunks and litem_start.
-// A workgroup owns the same ITEM_BLOCK_AIDS aids as in k_aid_totals; its base prefixes are the sums of the earlier
-// blocks' partials, the prefixes inside the block are block scans in aid order.
+// A workgroup owns the same ITEM_BLOCK_AIDS aids as in k_aid_totals; its base prefixes come from k_item_part_scan over the
+// workgroups' partial sums, the prefixes inside the block are block scans in aid order.
 struct ItemFillArgs {
     const uint64_t* cnt64;
     const uint8_t* boost;
     uint32_t n_aids;
     uint32_t l_cap;
     int allow_packed;
-    const unsigned long long* block_part;
+    const unsigned long long* block_part;   // [workgroup][N_ITEM_SCANS] exclusive prefixes
     uint64_t* items[3];
     uint32_t* order[3];
     uint64_t n_pilots[3];
     uint64_t* chunks;
     uint64_t* litem_start;     // [n_aids + 1]
 };
+// block_part[b][q] -> sum over the workgroups before b (in place): ten columns, one wave each walks its column in strides of 64
+__global__ __launch_bounds__(64 * N_ITEM_SCANS) void k_item_part_scan(unsigned long long* block_part, uint32_t nblk) {
+    const int q = threadIdx.x >> 6;
+    const unsigned lane = lane_id();
+    unsigned long long run = 0;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += 64) {
+        const uint32_t b = b0 + lane;
+        const unsigned long long v = b < nblk ? block_part[(size_t)b * N_ITEM_SCANS + q] : 0ull;
+        const unsigned long long inc = wave_incl_scan(v);
+        if (b < nblk) block_part[(size_t)b * N_ITEM_SCANS + q] = run + inc - v;
+        run += (unsigned long long)__shfl((unsigned long long)inc, 63, 64);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_items_fill(ItemFillArgs a) {
     __shared__ unsigned long long s_base[N_ITEM_SCANS];
     __shared__ uint64_t s_sc[256 / 64 + 1];
-    if (threadIdx.x < N_ITEM_SCANS) s_base[threadIdx.x] = 0;
-    __syncthreads();
-    {
-        unsigned long long acc[N_ITEM_SCANS];
-#pragma unroll
-        for (int q = 0; q < N_ITEM_SCANS; ++q) acc[q] = 0;
-        for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256)
-#pragma unroll
-            for (int q = 0; q < N_ITEM_SCANS; ++q) acc[q] += a.block_part[(size_t)j * N_ITEM_SCANS + q];
-#pragma unroll
-        for (int q = 0; q < N_ITEM_SCANS; ++q) {
-            unsigned long long v = acc[q];
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane_id() == 0 && v) atomicAdd(&s_base[q], v);
-        }
-    }
+    if (threadIdx.x < N_ITEM_SCANS) s_base[threadIdx.x] = a.block_part[(size_t)blockIdx.x * N_ITEM_SCANS + threadIdx.x];   // exclusive prefixes (k_item_part_scan)
     __syncthreads();
     // running prefixes (order of totals [8, 18)): [0..2] items per bin, [3..5] heavy items per layout, [6..8] heavy aids per layout, [9] chunks
     uint64_t run[N_ITEM_SCANS];
@@ -3175,6 +3174,7 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
         fa.chunks = c->chunks.as<uint64_t>();
         OTTO_TRY(c->litem_start.ensure((size_t)(n_aids + 1) * 8, 0, s));
         fa.litem_start = c->litem_start.as<uint64_t>();
+        k_item_part_scan<<<1, 64 * N_ITEM_SCANS, 0, s>>>(c->item_part.as<unsigned long long>(), (uint32_t)item_blocks);
         k_items_fill<<<item_blocks, 256, 0, s>>>(fa);
         OTTO_HIP(hipGetLastError());
     }
