@@ -396,6 +396,45 @@ def test_device_frame_to_events_equals_numpy_path(gpu_device, variant):
     assert np.array_equal(got.order.cpu().numpy().view(np.uint32), order.astype(np.uint32))
 
 
+def test_device_event_sort_of_millions_of_rows_is_the_stable_sort(gpu_device):
+    """The radix sort at a size where every workgroup walks several tiles and the digit offsets cross many workgroups
+    (6 M rows, sparse session ids, coarse timestamps = many ties): permutation, sorted columns, CSR and session ids equal
+    to a stable sort of (session, seconds) done by torch on the same device."""
+    import ctypes as C
+    from otto_amd import _lib
+    n, n_sess = 6_000_011, 400_000
+    g = torch.Generator(device=gpu_device)
+    g.manual_seed(9)
+    sess = (torch.randint(0, n_sess, (n,), device=gpu_device, generator=g) * 13 + 5_000_000).to(torch.int32)
+    ts_ms = (1_659_304_800 + torch.randint(0, 3000, (n,), device=gpu_device, generator=g) * 600).to(torch.int64) * 1000 + 17
+    aid = torch.randint(0, 1_855_603, (n,), device=gpu_device, generator=g).to(torch.int32)
+    typ = torch.randint(0, 3, (n,), device=gpu_device, generator=g).to(torch.uint8)
+    lib = _lib.lib()
+    ws_b = lib.otto_events_sort_workspace(n)
+    ws = torch.empty(int(ws_b), dtype=torch.uint8, device=gpu_device)
+    o_aid = torch.empty(n, dtype=torch.int32, device=gpu_device)
+    o_ts = torch.empty(n, dtype=torch.int32, device=gpu_device)
+    o_type = torch.empty(n, dtype=torch.uint8, device=gpu_device)
+    o_order = torch.empty(n, dtype=torch.int32, device=gpu_device)
+    o_off = torch.empty(n + 1, dtype=torch.int64, device=gpu_device)
+    o_id = torch.empty(n, dtype=torch.int32, device=gpu_device)
+    ns = C.c_int64()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    with torch.cuda.device(gpu_device):
+        _lib.check(lib.otto_events_sort(p(sess), p(ts_ms), p(aid), p(typ), n, 1000, p(o_aid), p(o_ts), p(o_type), p(o_order), p(o_off), p(o_id),
+                                        C.byref(ns), p(ws), int(ws_b), C.c_void_p(torch.cuda.current_stream(gpu_device).cuda_stream)),
+                   'otto_events_sort')
+    sec = ts_ms // 1000
+    key = sess.to(torch.int64) * (1 << 32) + sec
+    want_order = torch.sort(key, stable=True).indices
+    assert torch.equal(o_order.to(torch.int64), want_order)
+    assert torch.equal(o_aid, aid[want_order]) and torch.equal(o_ts.to(torch.int64), sec[want_order]) and torch.equal(o_type, typ[want_order])
+    ids, counts = torch.unique_consecutive(sess[want_order], return_counts=True)
+    S = int(ns.value)
+    assert S == ids.numel() and torch.equal(o_id[:S], ids)
+    assert torch.equal(o_off[:S + 1], torch.cat([torch.zeros(1, dtype=torch.int64, device=gpu_device), torch.cumsum(counts, 0)]))
+
+
 def test_device_ingest_rejects_unknown_type_strings_and_handles_empty(gpu_device):
     from otto_amd import _lib
     from otto_amd.events import frame_to_events_device
