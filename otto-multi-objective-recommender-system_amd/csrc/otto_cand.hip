@@ -20,7 +20,8 @@ namespace otto {
 
 constexpr uint64_t CD_EMPTY = ~0ull;
 constexpr int CD_EXCAP = 64;
-constexpr int CD_SMALL_MAXL = 32;                     // sessions up to this many events run in the small-footprint variant
+constexpr int CD_SMALL_MAXL = 32;
+constexpr int CD_STACK = 96;                          // partitions waiting (first level <= 64) + refinements                     // sessions up to this many events run in the small-footprint variant
 
 struct CandArgs {
     otto_cand_params p;
@@ -43,7 +44,7 @@ __device__ __forceinline__ uint64_t cand_key(uint64_t count, uint32_t fp, uint32
 // Two instantiations share the code: <32, 10, 128> for short sessions (16 KB of LDS: ten workgroups per CU instead of
 // two -- most sessions are short and the per-session phases are barrier / latency bound) and <500, 12, 256> for the rest.
 template <int CD_MAXL, int CD_LOG2T, int CD_THREADS>
-__global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
+__global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(CandArgs a) {
     constexpr int CD_NW = CD_THREADS / 64;
     constexpr int CD_T = 1 << CD_LOG2T;
     constexpr int CD_CAP = CD_T / 4 * 3;                 // list entries per hash partition (load <= 3/4)
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
     __shared__ uint64_t s_lb[CD_THREADS];
     __shared__ uint64_t s_ex[CD_EXCAP];
     __shared__ uint64_t s_thr;
-    __shared__ uint32_t s_nex, s_more, s_ovf, s_scan[CD_NW + 1], s_keep[2];
+    __shared__ uint32_t s_nex, s_more, s_ovf, s_nfresh, s_sp, s_scan[CD_NW + 1], s_keep[2];
+    __shared__ uint32_t s_stack[CD_STACK];            // hash partitions still to do: id | level << 24
 
     const int tid = threadIdx.x, wid = tid >> 6;
     const unsigned lane = lane_id();
@@ -152,21 +154,43 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
         const int lt = (1 << lt1) < CD_THREADS ? CD_LOG2T : lt1;       // at least one table slot per thread
         const int Teff = 1 << lt;
         const int mpl = Teff / CD_THREADS;                    // table slots per thread: 1, 4 or 16
-        int lgR = 0;
-        while (((uint32_t)CD_CAP << lgR) < TOT) ++lgR;
-        __syncthreads();
-        // ---- C + D per hash partition (if a partition ever fills the table: start over with twice as many) ----------
-        for (bool again = true; again; ++lgR) {
-        again = false;
-        const uint32_t R = 1u << lgR;
-        if (tid == 0) s_ovf = 0;
+        // ---- C + D per hash partition. A partition may hold CD_CAP DISTINCT aids; the lists of a session overlap heavily (the
+        //      same source aid in several matrices, neighbouring aids with common partners), so the first level is sized for
+        //      half the entries, and a partition that still collects more than CD_CAP distinct aids is split in two (one more
+        //      hash bit) and only ITS entries are gathered again. Partitions hold disjoint aids: each one merges its
+        //      most_common(n_common) into the running list s_sel, in any order.
+        int lg0 = 0;
+        // Recipes that read three or more matrices through the same source list (the click recipes) always start at half; the
+        // others only where that can save two passes or more (up to two tables' worth of entries: two partitions as before).
+        int same_src = 0;
+        for (int t = 0; t < a.p.n_terms; ++t) {
+            int c = 0;
+            for (int u = 0; u < a.p.n_terms; ++u) c += a.p.term_source[u] == a.p.term_source[t] ? 1 : 0;
+            same_src = c > same_src ? c : same_src;
+        }
+        const uint32_t opt_from = same_src >= 3 ? (uint32_t)CD_CAP : 2u * (uint32_t)CD_CAP;
+        while (((uint32_t)CD_CAP << lg0) < (TOT <= opt_from ? TOT : TOT / 2u) && lg0 < 6) ++lg0;
+        if (tid == 0) {
+            s_sp = 1u << lg0;
+            for (uint32_t pp = 0; pp < (1u << lg0); ++pp) s_stack[pp] = pp | ((uint32_t)lg0 << 24);
+        }
         for (int i = tid; i < NC; i += CD_THREADS) s_sel[i] = 0;
+        bool have_sel = false;                                // s_sel holds the merged result of at least one partition
         __syncthreads();
-        for (uint32_t part = 0; part < R; ++part) {
+        for (;;) {
+            const uint32_t sp = s_sp;
+            if (sp == 0) break;
+            const uint32_t ent = s_stack[sp - 1];
+            const uint32_t part = ent & 0xFFFFFFu;
+            const int lgR = (int)(ent >> 24);
+            const uint32_t R = 1u << lgR;
+            __syncthreads();
+            if (tid == 0) { s_sp = sp - 1; s_ovf = 0; s_nfresh = 0; }
             for (int i = tid; i < Teff; i += CD_THREADS) { s_tab[i] = CD_EMPTY; s_fp[i] = 0xFFFFFFFFu; }
             __syncthreads();
             const int hw = tid >> 5, l = tid & 31;
             for (uint32_t q = hw; q < Q; q += CD_THREADS / 32) {
+                if (s_ovf) break;                             // the partition is being split: its table is not used
                 const uint32_t b = s_base[q];
                 const uint32_t len = b >> 24, base = b & 0xFFFFFFu;
                 for (uint32_t l2 = (uint32_t)l; l2 < len; l2 += 32u) {      // lists longer than 32 (neighbour lists): two rounds
@@ -186,6 +210,7 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
                             const bool fresh = old == CD_EMPTY;
                             if (fresh || (uint32_t)(old >> 32) == y) {
                                 if (!fresh) atomicAdd(&s_tab[slot], 1ull);
+                                else if (TOT > (uint32_t)CD_CAP && atomicAdd(&s_nfresh, 1u) >= (uint32_t)CD_CAP) s_ovf = 1;   // too full to probe cheaply
                                 atomicMin(&s_fp[slot], base + l2);
                                 placed = true;
                                 break;
@@ -197,7 +222,18 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
                 }
             }
             __syncthreads();
-            if (s_ovf) { again = true; break; }
+            if (s_ovf) {                                      // split this partition: one more hash bit, two children
+                if (tid == 0) {
+                    if (lgR + lt >= 32 || sp + 1 > (uint32_t)CD_STACK) atomicAdd(a.err, 1u << 16);      // cannot happen below 2^20 equal hash prefixes
+                    else {
+                        s_stack[sp - 1] = (part << 1) | ((uint32_t)(lgR + 1) << 24);
+                        s_stack[sp] = ((part << 1) | 1u) | ((uint32_t)(lgR + 1) << 24);
+                        s_sp = sp + 1;
+                    }
+                }
+                __syncthreads();
+                continue;
+            }
             if (a.self_count) {
                 // the session's own aids: report their counts, then take them out of the selection (count 0 = tombstone: the
                 // slot stays occupied for the probes of the other aids)
@@ -234,7 +270,7 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
                     if (v != CD_EMPTY && (v & 0xFFFFFFFFull) != 0) k.c = cand_key(v & 0xFFFFFFFFull, s_fp[i], (uint32_t)(v >> 32));
                 } else {
                     const int i = tid + (q - mpl) * CD_THREADS;
-                    if (part > 0 && i < NC) k.c = s_sel[i];
+                    if (have_sel && i < NC) k.c = s_sel[i];
                 }
                 return k;
             };
@@ -310,10 +346,10 @@ __global__ __launch_bounds__(CD_THREADS) void k_cand(CandArgs a) {
                 s_sel[lane] = selA;
                 if (64 + (int)lane < NC) s_sel[64 + lane] = selB;
             }
+            have_sel = true;
             __syncthreads();
         }
         __syncthreads();
-        }
         // ---- drop the session's own aids, compact, write ---------------------------------------------------
         const uint32_t nU = s_nsrc[0];
         bool keep = false;
