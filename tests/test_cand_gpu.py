@@ -208,3 +208,54 @@ def test_recency_branch_predictions_with_neighbour_and_list_bumps(gpu_device):
                 assert (pred[t, s, n[t, s]:] == -1).all()
             checked += 1
         assert checked >= (20 if min_unique == 20 else 800), checked
+
+
+def test_edge_cases_of_the_next_row_entry_points(gpu_device):
+    """Degenerate inputs through the new C-ABI entry points: sessions of one event and of one repeated aid through the
+    recency branch (with and without a neighbour table), an all-empty candidate row and a one-event session through the
+    interaction features, single-event sessions through the aid-pair builders (no pairs), and argument errors."""
+    import torch
+    import recency_oracle as ro
+    from otto_amd import _lib
+    from otto_amd.covisitation import candidates as cd
+    from otto_amd.events import DeviceEvents
+    from otto_amd.matrix_factorization.data import build_aid_pairs_device
+    from otto_amd.ranker import interaction_feature_engineering as ife
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(gpu_device)
+    # sessions: [7], [3 3 3 3], [1 2 1 2 5]
+    aid = np.array([7, 3, 3, 3, 3, 1, 2, 1, 2, 5], dtype=np.int32)
+    typ = np.array([0, 0, 1, 2, 0, 0, 1, 0, 2, 0], dtype=np.uint8)
+    off = np.array([0, 1, 5, 10], dtype=np.int64)
+    n_aids, k = 10, 4
+    rng = np.random.default_rng(3)
+    def mat():
+        return (t(rng.integers(0, n_aids, (n_aids, k)).astype(np.int32)), None, t(rng.integers(0, k + 1, n_aids).astype(np.int32)))
+    mats = {'time_weighted': mat(), 'cart_weighted': mat(), 'cart_order': mat(), 'neighbours': mat()}
+    top = {kind: cdo.matrix_to_dict(m[0].cpu().numpy(), m[-1].cpu().numpy()) for kind, m in mats.items()}
+    for nb_name, nbd in (('neighbours', top['neighbours']), (None, {})):
+        pred, w, n = (x.cpu().numpy() for x in cd.recency_predictions(t(aid), t(typ), t(off), mats, neighbours=nb_name, min_unique=1))
+        for s in range(3):
+            want = ro.session_recency_predictions(aid[off[s]:off[s + 1]], typ[off[s]:off[s + 1]], top, nbd)
+            for tg, (wa, ww) in enumerate(want):
+                assert n[tg, s] == len(wa) and pred[tg, s, :n[tg, s]].tolist() == wa, (nb_name, s, tg)
+                np.testing.assert_allclose(w[tg, s, :n[tg, s]], np.array(ww), rtol=1e-12, atol=0)
+    pred, w, n = cd.recency_predictions(t(aid), t(typ), t(off), mats, min_unique=50)
+    assert (n.cpu().numpy() == -1).all() and (pred.cpu().numpy() == -1).all()       # nobody has 50 unique aids
+    # interaction features: empty candidate row, candidates that never occur, a one-event session
+    cand = np.array([[-1, -1, -1], [3, 9, -1], [2, 1, 8]], dtype=np.int32)
+    score = np.array([[0, 0, 0], [2, 1, 0], [1, 1, 5]], dtype=np.float32)
+    row, sf, af = (x.cpu().numpy() for x in ife.interaction_features(t(aid), t(typ), t(off), t(cand), t(score), n_aids))
+    assert np.isnan(sf[0]).all()                                                     # no candidate rows: every aggregate is null
+    assert row[1, 0].tolist() == [4, 4, 2, 1, 1] and row[1, 1].tolist() == [0, 0, 0, 0, 0]     # aid 3: 4 events, last at 4; aid 9 absent
+    assert row[2, 0].tolist() == [2, 4, 0, 1, 1] and row[2, 1].tolist() == [2, 3, 2, 0, 0]
+    assert np.isnan(af[7]).all() and af[9][3] == 0.0                                 # aid 7 is nobody's candidate; aid 9 never occurs
+    # aid-pair builders: only one-event sessions -> no pairs at all
+    one = DeviceEvents(t(np.array([4, 5, 6], dtype=np.int32)), t(np.array([10, 20, 30], dtype=np.int32)), t(np.zeros(3, dtype=np.uint8)),
+                       t(np.array([0, 1, 2, 3], dtype=np.int64)), t(np.arange(3)), None, n_aids)
+    for strat in ('diff', 'time'):
+        x1, x2, tg = build_aid_pairs_device(one, strat, sample_frac=1.0)
+        assert x1.numel() == 0 and x2.numel() == 0 and tg.numel() == 0
+    with pytest.raises(ValueError):
+        build_aid_pairs_device(one, 'nearest')
+    with pytest.raises(_lib.OttoError):
+        cd.recency_predictions(t(aid), t(typ), t(off), mats, n_pred=200)             # n_pred <= 64
