@@ -482,3 +482,13 @@ def test_device_aid_pair_builders_equal_host_builders(gpu_device):
     assert all(torch.equal(x, y) for x, y in zip(a, b)) and 0 < a[0].numel() < g.shape[0] * 10
     with pytest.raises(ValueError):
         build_aid_pairs_device(dev_ev, 'nope')
+    # 'diff' again at a size where the sorts inside span many workgroups (1 M events, 2 M raw records)
+    big = generate_sessions(60000, n_aids=20000, seed=22)
+    bfr = big.to_frame()
+    bdev = frame_to_events_device(bfr, device=gpu_device, n_aids=20000)
+    bkeys = np.random.default_rng(4).integers(0, 2 ** 31, big.n_events, dtype=np.uint64)
+    want = build_aid_pairs(bfr, 'diff', shuffle_keys=bkeys)
+    got = build_aid_pairs_device(bdev, 'diff', shuffle_keys=bkeys)
+    g = rows([c.cpu().numpy() for c in got])
+    w = rows([want['x1'], want['x2'], want['target']])
+    assert g.shape == w.shape and np.array_equal(g, w)
