@@ -106,6 +106,26 @@ __global__ void k_fill_classes(const uint8_t* cls, int64_t n_sess, ClassFill f, 
 // run_x of a run slot without records (a repeated aid of a window): the index passes skip it without reading its descriptor
 constexpr uint32_t RUN_X_EMPTY = 0xFFFFFFFFu;
 
+// Run descriptor (u64): len (bits 0-5, <= 32) | first record slot << 8 (40 bits) | sp << 48 (6 bits); 0 = empty run.
+// sp: the run reads a SHARED list (the distinct aids of one time-connected component of the window, written once and
+// read by the run of every aid in it) and sp is the position of the run's own aid inside that list -- the gather
+// skips it; the time extra of such a run is ONE value, kept at tw[slot + sp]. sp = 63: a private row (every record
+// is a pair, the time extra is per record).
+constexpr int DESC_SLOT_BITS = 40;
+constexpr uint64_t DESC_SLOT_MASK = (1ull << DESC_SLOT_BITS) - 1ull;
+constexpr uint32_t DESC_SP_NONE = 63u;
+__host__ __device__ __forceinline__ uint64_t make_desc(uint64_t slot, uint32_t len, uint32_t sp = DESC_SP_NONE) {
+    return len ? ((uint64_t)len | (slot << 8) | ((uint64_t)sp << 48)) : 0ull;
+}
+__host__ __device__ __forceinline__ uint32_t desc_len(uint64_t d) { return (uint32_t)d & 0x3Fu; }
+__host__ __device__ __forceinline__ uint64_t desc_slot(uint64_t d) { return (d >> 8) & DESC_SLOT_MASK; }
+__host__ __device__ __forceinline__ uint32_t desc_sp(uint64_t d) { return (uint32_t)(d >> 48) & 63u; }
+// pairs the run contributes (the list entry of the run's own aid is not a pair)
+__host__ __device__ __forceinline__ uint32_t desc_pairs(uint64_t d) {
+    const uint32_t len = desc_len(d);
+    return len - ((len && desc_sp(d) != DESC_SP_NONE) ? 1u : 0u);
+}
+
 struct ExpandArgs {
     const uint32_t* aid;
     const int32_t* ts;
@@ -121,6 +141,7 @@ struct ExpandArgs {
     uint64_t* run_desc;
     uint64_t rec_base;           // first record / run slot of this chunk
     uint64_t run_base;
+    uint64_t list_base;          // k_expand_lists: first list slot of this chunk (behind its pair slots)
     int window;
     int max_gap;
     int64_t t0;
@@ -263,7 +284,7 @@ __global__ __launch_bounds__(256) void k_expand(ExpandArgs a) {
         }
         if (g < n) {
             a.run_x[a.run_base + ebase + g] = my_cnt ? aid : RUN_X_EMPTY;
-            a.run_desc[a.run_base + ebase + g] = my_cnt ? (((a.rec_base + pbase + my_off) << 8) | my_cnt) : 0ull;
+            a.run_desc[a.run_base + ebase + g] = make_desc(a.rec_base + pbase + my_off, my_cnt);
         }
         wave_lds_sync();
     }
@@ -345,7 +366,7 @@ __global__ __launch_bounds__(256) void k_expand_fast(ExpandArgs a) {
         if (g < n) {
             const bool has = rep && d > 1;
             a.run_x[a.run_base + ebase + g] = has ? aid : RUN_X_EMPTY;
-            a.run_desc[a.run_base + ebase + g] = has ? (((a.rec_base + pbase + (uint64_t)below * (d - 1)) << 8) | (d - 1)) : 0ull;
+            a.run_desc[a.run_base + ebase + g] = make_desc(a.rec_base + pbase + (uint64_t)below * (d - 1), has ? d - 1 : 0u);
         }
         wave_lds_sync();
     }
@@ -466,7 +487,7 @@ __device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, 
         }
         if (act) {
             a.run_x[a.run_base + ebase + g] = (rep && d1) ? aid : RUN_X_EMPTY;
-            a.run_desc[a.run_base + ebase + g] = (rep && d1) ? (((a.rec_base + pbase + (uint64_t)below * d1) << 8) | d1) : 0ull;
+            a.run_desc[a.run_base + ebase + g] = make_desc(a.rec_base + pbase + (uint64_t)below * d1, rep ? d1 : 0u);
         }
         wave_lds_sync();
         return;
@@ -508,7 +529,7 @@ __device__ __forceinline__ void expand_task_reg(const ExpandArgs& a, uint4* ev, 
     if (act) {
         const uint32_t len = rep ? __popc(done) : 0u;
         a.run_x[a.run_base + ebase + g] = len ? aid : RUN_X_EMPTY;
-        a.run_desc[a.run_base + ebase + g] = len ? (((a.rec_base + pbase + rb) << 8) | len) : 0ull;
+        a.run_desc[a.run_base + ebase + g] = make_desc(a.rec_base + pbase + rb, len);
     }
     wave_lds_sync();
 }
@@ -602,6 +623,267 @@ __global__ __launch_bounds__(256) void k_expand_fused(ExpandArgs a, int64_t n_se
     }
 }
 
+// ---- component lists (no filter kinds): a window's pairs WITHOUT writing one record per pair ---------------------
+// Events of a session arrive sorted by time, so "valid pair" (|dt| <= max_gap) is a band over the window positions.
+// Cut the window where two neighbouring events are more than max_gap apart: pairs across a cut are invalid, and a
+// piece ("component") whose whole time span is <= max_gap is a clique -- every two events of it are a valid pair
+// (OTTO shape: 99 % of the windows consist of cliques only; a gap-free window is the one-component case). Then
+//   * the first valid pair (i, j) of (x, y) in lexicographic order lies in the EARLIEST component that holds both:
+//     i = first x there, j = first y there;
+//   * so the row of x inside a component is the component's list of distinct aids (each with the type of its first
+//     event in the component) minus x itself, minus the aids y that already met x in an earlier component.
+// The list is written ONCE per component (one store per first occurrence: <= n words per window instead of n(n-1)),
+// and the run descriptor of every aid in it points at the shared list with the position of its own entry (sp), which
+// the gather skips. Only an aid with a repeated partner (x and y together in two components: 2.4 % of the runs of
+// multi-component windows) gets a private row, written by the component's lanes in one step. Windows with a component
+// that is not a clique, or with unsorted timestamps (1 % of the windows), take the general row loop of
+// expand_task_reg into private rows. The time extra of a shared run is ONE value (the first event of x in the
+// component): tw[list slot of x's own entry].
+// Slots: lists live behind the chunk's pair slots at list_base + ev_base[s] (n per window, dense: neighbouring
+// windows share cache lines); private rows keep the window's old region [pair_base[s], +n(n-1)).
+template <int G, bool TIME, bool DBG>
+__device__ __forceinline__ void expand_task_lists(const ExpandArgs& a, uint4* ev, unsigned lane, const TaskPre& tp) {
+    constexpr int WPW = 64 / G;
+    const int n = tp.n;
+    const uint64_t pbase = tp.pb, ebase = tp.eb;
+    const int g = (int)(lane & (G - 1));
+    const unsigned w0 = lane - g;                               // first lane of my window
+    uint4* evw = ev + w0;
+    int nmax = 0;
+#pragma unroll
+    for (int q = 0; q < WPW; ++q) {
+        const int nq = __builtin_amdgcn_readlane(n, q * G);
+        nmax = nq > nmax ? nq : nmax;
+    }
+    const int nmax4 = (nmax + 3) & ~3;
+    const bool act = g < n;
+    const uint32_t aid = tp.aid, ty = tp.ty;
+    const int32_t t = tp.t;
+    uint32_t extra = 0;
+    if (TIME && act) extra = a.tspan > 0 ? (uint32_t)((uint64_t)(196608ull * (uint64_t)((int64_t)t - a.t0)) / (uint64_t)a.tspan) : 0u;
+    ev[lane] = make_uint4(aid, (uint32_t)t, 0u, extra);
+    wave_lds_sync();
+    uint32_t same = 0;                                          // window-relative bits: events holding my aid
+    if (!(DBG && (a.debug & 4))) {
+        for (int j0 = 0; j0 < nmax4; j0 += 4) {
+            uint32_t ax[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ax[u] = evw[(j0 + u) & (G - 1)].x;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) same |= (ax[u] == aid ? 1u : 0u) << ((j0 + u) & 31);
+        }
+    } else same = 1u << g;
+    same &= n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    // a wave mask restricted to my window, bit 0 = the window's first lane
+    const bool hi_half = lane >= 32u;
+    auto win32 = [&](uint64_t m) -> uint32_t {
+        uint32_t h = hi_half ? (uint32_t)(m >> 32) : (uint32_t)m;
+        if (G < 32) h = (h >> (w0 & 31u)) & ((1u << (G & 31)) - 1u);
+        return h;
+    };
+    const uint32_t lem = (2u << g) - 1u, ltm = (1u << g) - 1u;     // window bits <= me / < me
+    // components: a new one starts where the previous event is more than max_gap older
+    const int32_t tprev = (int32_t)ev[(lane - 1u) & 63u].y;
+    const bool unsorted = act && g > 0 && t < tprev;
+    const bool bnd = act && (g == 0 || (uint32_t)(t - tprev) > (uint32_t)a.max_gap);
+    const uint32_t Bw = win32(__ballot(bnd));
+    const uint32_t cs = act ? 31u - (uint32_t)__clz((int)(Bw & lem)) : 0u;                 // first position of my component
+    const uint32_t above = (Bw & ~lem) | (n < 32 ? (1u << (n & 31)) : 0u);
+    const uint32_t ce = above ? (uint32_t)__builtin_ctz(above) : 32u;                      // one past its last position
+    const uint32_t ltc = (1u << cs) - 1u;                                                  // window bits before my component
+    const uint32_t cm = act ? ((0xFFFFFFFFu >> ((32u - ce) & 31u)) & ~ltc) : 0u;
+    const int32_t tcs = (int32_t)evw[cs].y;
+    const bool viol = unsorted || (act && (uint32_t)(t - tcs) > (uint32_t)a.max_gap);      // my component is not a clique
+    const bool general = win32(__ballot(viol)) != 0u;                                      // whole window: general row loop
+    const bool repc = act && !general && ((same & cm) & ltm) == 0u;                        // first event of my aid in my component
+    const uint32_t Rw = win32(__ballot(repc));
+    const uint32_t dc = (uint32_t)__popc(Rw & cm);                                         // entries of my component's list
+    const uint32_t lpos = (uint32_t)__popc(Rw & ltm);                                      // my entry inside the window's lists
+    const uint32_t lb = (uint32_t)__popc(Rw & ltc);                                        // first entry of my component's list
+    const uint64_t L0 = a.list_base + ebase;
+    const uint32_t word = aid | (ty << REC_AID_BITS);
+    if (repc && !(DBG && (a.debug & 1))) {
+        a.rec[L0 + lpos] = word;
+        if (TIME) a.tw[L0 + lpos] = extra;
+    }
+    // repeated partners: x (first event in component c) met y in an earlier component
+    const uint32_t E = same & ltc;                                                         // my aid in earlier components
+    const bool reocc = repc && E != 0u;
+    uint64_t RO = __ballot(reocc);
+    bool priv = false;
+    uint32_t poff = 0, pslot = 0, plen = 0;                                                // private rows of my window so far
+    if (RO != 0 && !(DBG && (a.debug & 2))) {
+        const uint32_t key = (uint32_t)__popc(Bw & lem) | (w0 << 5);                       // (window, component)
+        uint32_t PC = 0;                                                                   // earlier components holding my aid
+        uint32_t Er = reocc ? E : 0u;
+        while (__ballot(Er != 0u) != 0) {
+            if (Er) {
+                const uint32_t e = (uint32_t)__builtin_ctz(Er);
+                Er &= Er - 1u;
+                PC |= 1u << (((uint32_t)__popc(Bw & ((2u << e) - 1u)) - 1u) & 31u);
+            }
+        }
+        while (RO != 0) {
+            const int L = __builtin_ctzll(RO);
+            RO &= RO - 1ull;
+            const uint32_t PCx = (uint32_t)__builtin_amdgcn_readlane((int)PC, L);
+            const uint32_t kx = (uint32_t)__builtin_amdgcn_readlane((int)key, L);
+            const bool incomp = repc && key == kx && (int)lane != L;                       // the other entries of x's list
+            const bool hit = incomp && (PC & PCx) != 0u;
+            if (__ballot(hit) == 0) continue;
+            const bool put = incomp && !hit;
+            const uint64_t EP = __ballot(put);
+            const uint32_t len = (uint32_t)__popcll(EP);
+            if (put && !(DBG && (a.debug & 1))) {
+                const uint64_t o = a.rec_base + pbase + poff + (uint32_t)__popcll(EP & ((1ull << lane) - 1ull));
+                a.rec[o] = word;
+                if (TIME) a.tw[o] = (uint32_t)__builtin_amdgcn_readlane((int)extra, L);
+            }
+            if ((int)lane == L) { priv = true; pslot = poff; plen = len; }
+            if ((lane ^ (unsigned)L) < (unsigned)G) poff += len;                            // lanes of x's window
+        }
+    }
+    // general windows: the row loop of expand_task_reg (first valid pair per (x class, y class), private rows)
+    uint32_t glen = 0, grb = 0;
+    const bool gact = act && general;
+    if (__ballot(gact) != 0) {
+        const uint64_t win64 = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << w0;
+        const uint64_t lw64 = win64 & ((1ull << lane) - 1ull);
+        const int cls = act ? (int)__builtin_ctz(same) : g;
+        const bool rep = gact && cls == g;
+        const uint64_t rep64 = __ballot(rep);
+        const uint32_t d1 = (uint32_t)__popcll(rep64 & win64) - 1u;
+        const uint32_t rb = (uint32_t)__popcll(rep64 & win64 & ((1ull << (w0 + cls)) - 1ull)) * d1;
+        reinterpret_cast<uint32_t*>(&ev[lane])[2] = (uint32_t)cls | (rb << 5);
+        wave_lds_sync();
+        const uint64_t same64 = (uint64_t)same << w0;
+        const uint64_t samelow64 = same64 & lw64;
+        const uint32_t nlim = gact ? (uint32_t)n : 0u;
+        int gmax = 0;
+#pragma unroll
+        for (int q = 0; q < WPW; ++q) {
+            const int nq = __builtin_amdgcn_readlane((int)nlim, q * G);
+            gmax = nq > gmax ? nq : gmax;
+        }
+        uint32_t done = 0;
+        uint4 e = evw[0];
+        uint32_t* recp = a.rec + (a.rec_base + pbase);
+        uint32_t* twp = TIME ? a.tw + (a.rec_base + pbase) : nullptr;
+        constexpr int NE = 33, EQ = 32, ULT = 36, ULE = 37;
+        for (int i = 0; i < gmax; ++i) {
+            const uint4 en = evw[(i + 1) & (G - 1)];
+            const uint32_t dA = e.y - (uint32_t)t, dB = (uint32_t)t - e.y;
+            const uint32_t ad = dA < dB ? dA : dB;
+            const uint64_t V = __builtin_amdgcn_uicmp((uint32_t)i, nlim, ULT) & __builtin_amdgcn_uicmp(e.x, aid, NE) &
+                               __builtin_amdgcn_uicmp(ad, (uint32_t)a.max_gap, ULE);
+            if (V != 0) {
+                const uint32_t bit = 1u << (e.z & 31u);
+                const uint64_t S = __builtin_amdgcn_uicmp(done & bit, 0u, NE);
+                const uint64_t M = __builtin_amdgcn_uicmpl(V & same64, 0ull, NE);
+                const uint64_t F = __builtin_amdgcn_uicmpl(V & samelow64, 0ull, EQ);
+                const uint64_t Em = V & ~S & F;
+                const uint64_t D = rep64 & S;
+                if (__builtin_amdgcn_inverse_ballot_w64(M)) done |= bit;
+                if (__builtin_amdgcn_inverse_ballot_w64(Em) && !(DBG && (a.debug & 1))) {
+                    const uint32_t o = (e.z >> 5) + (uint32_t)__popcll(D & win64) + (uint32_t)__popcll(Em & lw64);
+                    recp[o] = word;
+                    if (TIME) twp[o] = e.w;
+                }
+            }
+            e = en;
+        }
+        glen = rep ? (uint32_t)__popc(done) : 0u;
+        grb = rb;
+    }
+    if (act) {
+        uint64_t d;
+        if (general) d = make_desc(a.rec_base + pbase + grb, glen);
+        else if (priv) d = make_desc(a.rec_base + pbase + pslot, plen);
+        else d = make_desc(L0 + lb, (repc && dc > 1u) ? dc : 0u, lpos - lb);
+        if (!(DBG && (a.debug & 8))) {
+            a.run_x[a.run_base + ebase + g] = d ? aid : RUN_X_EMPTY;
+            a.run_desc[a.run_base + ebase + g] = d;
+        }
+    }
+    wave_lds_sync();
+}
+
+// One launch over the sessions in memory order (as k_expand_fused): 64 sessions per wave round, sorted with ballots
+// into three window size classes (n <= 8 / 16 / 32 -> 8 / 16 / 32 lanes per window) in a wave-private LDS task list.
+template <bool TIME, bool DBG>
+__global__ __launch_bounds__(256) void k_expand_lists(ExpandArgs a, int64_t n_sess) {
+    __shared__ uint4 s_ev[4][64];
+    __shared__ uint4 s_ta[4][64];       // task: wstart lo, wstart hi | n << 16, pair_base lo, hi
+    __shared__ uint2 s_tb[4][64];       //       ev_base lo, hi
+    const int wv = threadIdx.x >> 6;
+    const unsigned lane = lane_id();
+    uint4* ev = s_ev[wv];
+    uint4* ta = s_ta[wv];
+    uint2* tb = s_tb[wv];
+    const int64_t n_tiles = (n_sess + 63) / 64;
+    const int64_t tile_stride = (int64_t)gridDim.x * 4;
+    struct TilePre { int64_t lo, hi; uint64_t pb, eb; };
+    auto fetch_tile = [&](int64_t tile) {
+        TilePre q;
+        q.lo = q.hi = 0; q.pb = q.eb = 0;
+        const int64_t s = tile * 64 + lane;
+        if (tile < n_tiles && s < n_sess) {
+            q.lo = a.sess_off[s]; q.hi = a.sess_off[s + 1];
+            q.pb = a.pair_base[s]; q.eb = a.ev_base[s];
+        }
+        return q;
+    };
+    int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+    TilePre cur = fetch_tile(tile);
+    for (; tile < n_tiles; tile += tile_stride) {
+        const TilePre nxt = fetch_tile(tile + tile_stride);
+        const int64_t len = cur.hi - cur.lo;
+        const int n = (int)(len < a.window ? len : a.window);
+        const int64_t wstart = cur.hi - n;
+        const int c3 = n >= 2 ? (n <= 8 ? 0 : (n <= 16 ? 1 : 2)) : 3;
+        int cnt[3], base[3];
+        int below = 0, acc = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const uint64_t m = __ballot(c3 == q);
+            cnt[q] = __popcll(m);
+            base[q] = acc;
+            if (c3 == q) below = acc + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            acc += cnt[q];
+        }
+        if (c3 < 3) {
+            ta[below] = make_uint4((uint32_t)wstart, (uint32_t)((uint64_t)wstart >> 32) | ((uint32_t)n << 16), (uint32_t)cur.pb, (uint32_t)(cur.pb >> 32));
+            tb[below] = make_uint2((uint32_t)cur.eb, (uint32_t)(cur.eb >> 32));
+        }
+        wave_lds_sync();
+        auto run_class = [&](auto gtag, auto gntag, int q, const TaskPre& first) {
+            constexpr int G = decltype(gtag)::value;
+            constexpr int GN = decltype(gntag)::value;
+            constexpr int WPW = 64 / G;
+            const int b0 = base[q], c = cnt[q];
+            const int bn = q < 2 ? base[q < 2 ? q + 1 : 2] : 0, cn = q < 2 ? cnt[q < 2 ? q + 1 : 2] : 0;
+            TaskPre tp = first;
+            for (int t0 = 0; t0 < c; t0 += WPW) {
+                TaskPre nx;
+                if (t0 + WPW < c) nx = fetch_task<G, true>(a, ta, tb, b0, c, t0 + WPW, lane);
+                else nx = fetch_task<GN, true>(a, ta, tb, bn, cn, 0, lane);
+                expand_task_lists<G, TIME, DBG>(a, ev, lane, tp);
+                tp = nx;
+            }
+            if (c == 0) tp = fetch_task<GN, true>(a, ta, tb, bn, cn, 0, lane);
+            return tp;
+        };
+        using I8 = std::integral_constant<int, 8>;
+        using I16 = std::integral_constant<int, 16>;
+        using I32 = std::integral_constant<int, 32>;
+        TaskPre tp = fetch_task<8, true>(a, ta, tb, base[0], cnt[0], 0, lane);
+        tp = run_class(I8{}, I16{}, 0, tp);
+        tp = run_class(I16{}, I32{}, 1, tp);
+        tp = run_class(I32{}, I32{}, 2, tp);
+        cur = nxt;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // index: histogram / scatter of runs by aid_x, work items
 // ---------------------------------------------------------------------------
@@ -614,12 +896,11 @@ __global__ void k_hist_runs(const uint32_t* run_x, const uint64_t* run_desc, int
                             uint32_t* run_rank, uint32_t n_aids) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t d = run_desc[i];
-        const uint64_t len = d & 0xFFull;
-        if (len) {
+        if (desc_len(d)) {
             const uint32_t x = run_x[i];
             if (x < n_aids) {
                 const unsigned long long old =
-                    atomicAdd((unsigned long long*)&cnt64[x], (unsigned long long)((1ull << CNT_REC_BITS) | len));
+                    atomicAdd((unsigned long long*)&cnt64[x], (unsigned long long)((1ull << CNT_REC_BITS) | desc_pairs(d)));
                 run_rank[i] = (uint32_t)(old >> CNT_REC_BITS);
             }
         }
@@ -731,7 +1012,7 @@ __global__ __launch_bounds__(BKT_THREADS) void k_bkt_fused(BktArgs a, uint64_t* 
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (d[u]) atomicAdd(&s_dyn[xl[u]], (1ull << CNT_REC_BITS) | (d[u] & 0xFFull));
+                if (d[u]) atomicAdd(&s_dyn[xl[u]], (1ull << CNT_REC_BITS) | desc_pairs(d[u]));
         }
         __syncthreads();
         // counts out, exclusive scan of the run counts over the bucket's aids (thread t: aids t * per .. + per)
@@ -794,7 +1075,7 @@ __global__ void k_scatter_runs(const uint32_t* run_x, const uint64_t* run_desc, 
                                const uint64_t* run_start, uint64_t* sorted_desc, uint32_t n_aids) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t d = run_desc[i];
-        if (d & 0xFFull) {
+        if (desc_len(d)) {
             const uint32_t x = run_x[i];
             if (x < n_aids) sorted_desc[run_start[x] + run_rank[i]] = d;
         }
@@ -1080,9 +1361,11 @@ __device__ __forceinline__ void for_each_record_batch(const uint64_t* sorted_des
             for (int u = 0; u < GATHER_U; ++u) {
                 const int src = t + 2 * u + half;
                 const uint64_t dd = (uint64_t)__shfl((unsigned long long)d, src & 63, 64);
-                sl[u] = (dd >> 8) + l;
-                ok[u] = src < 64 && l < (uint32_t)(dd & 0xFFull);
-                rc[u] = ok[u] ? rec[sl[u]] : 0u;
+                const uint32_t sp = desc_sp(dd);
+                const uint64_t s0 = desc_slot(dd);
+                ok[u] = src < 64 && l < desc_len(dd) && l != sp;               // the run's own list entry is not a pair
+                rc[u] = ok[u] ? rec[s0 + l] : 0u;
+                sl[u] = s0 + (sp != DESC_SP_NONE ? sp : l);                      // where the record's time extra lives
             }
         };
         auto consume = [&](uint32_t (&rc)[GATHER_U], uint64_t (&sl)[GATHER_U], bool (&ok)[GATHER_U]) { fb(rc, sl, ok); };
@@ -1119,7 +1402,7 @@ __device__ __forceinline__ void for_each_record_seg(const uint64_t* sorted_desc,
     for (uint64_t cb = r0; cb < r1; cb += (uint64_t)NW * 64) {
         const uint64_t cbn = cb + (uint64_t)NW * 64;
         const uint64_t dn = cbn < r1 ? load_desc(cbn) : 0ull;              // next descriptors in flight
-        const uint32_t len = (uint32_t)(d & 0xFFull);
+        const uint32_t len = desc_len(d);
         const uint32_t segs = (len + 7u) >> 3;
         const uint32_t incl = wave_incl_scan(segs), excl = incl - segs;
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -1139,10 +1422,11 @@ __device__ __forceinline__ void for_each_record_seg(const uint64_t* sorted_desc,
                 const uint32_t r = has ? (uint32_t)s_seg[q] : 0u;
                 const uint64_t dd = (uint64_t)__shfl((unsigned long long)d, (int)(r & 63u), 64);
                 const uint32_t off = (r >> 6) * 8u + gl;
-                const uint64_t slot = (dd >> 8) + off;
-                if (NEED_SL) sl[NEED_SL ? u : 0] = slot;
-                ok[u] = has && off < (uint32_t)(dd & 0xFFull);
-                rc[u] = ok[u] ? rec[slot] : 0u;
+                const uint32_t sp = desc_sp(dd);
+                const uint64_t s0 = desc_slot(dd);
+                if (NEED_SL) sl[NEED_SL ? u : 0] = s0 + (sp != DESC_SP_NONE ? sp : off);   // where the record's time extra lives
+                ok[u] = has && off < desc_len(dd) && off != sp;                // the run's own list entry is not a pair
+                rc[u] = ok[u] ? rec[s0 + off] : 0u;
             }
         };
         if (nstep > 0) issue(0, rcA, slA, okA);
@@ -2562,7 +2846,7 @@ struct ExportRuns {   // 1 if run slot i leaves for [lo, hi)
     uint32_t lo, hi;
     __device__ uint64_t operator()(int64_t i) const {
         const uint32_t x = run_x[i];
-        return ((run_desc[i] & 0xFFull) && x >= lo && x < hi) ? 1ull : 0ull;
+        return (desc_len(run_desc[i]) && x >= lo && x < hi) ? 1ull : 0ull;
     }
 };
 struct ExportRecs {
@@ -2571,7 +2855,7 @@ struct ExportRecs {
     uint32_t lo, hi;
     __device__ uint64_t operator()(int64_t i) const {
         const uint32_t x = run_x[i];
-        const uint64_t len = run_desc[i] & 0xFFull;
+        const uint64_t len = desc_pairs(run_desc[i]);               // exported runs are private rows: pairs only
         return (len && x >= lo && x < hi) ? len : 0ull;
     }
 };
@@ -2581,15 +2865,16 @@ __global__ void k_export(const uint32_t* run_x, const uint64_t* run_desc, int64_
                          uint32_t* o_hdr, uint32_t* o_rec, uint32_t* o_tw) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t d = run_desc[i];
-        const uint32_t len = (uint32_t)(d & 0xFFull);
+        const uint32_t len = desc_pairs(d), sp = desc_sp(d);
         const uint32_t x = run_x[i];
         if (len && x >= lo && x < hi) {
-            const uint64_t rp = run_pos[i], cp = rec_pos[i], off = d >> 8;
+            const uint64_t rp = run_pos[i], cp = rec_pos[i], off = desc_slot(d);
             o_hdr[2 * rp] = x;
             o_hdr[2 * rp + 1] = len;
             for (uint32_t t = 0; t < len; ++t) {
-                o_rec[cp + t] = rec[off + t];
-                if (o_tw) o_tw[cp + t] = tw[off + t];
+                const uint32_t pos = t >= sp ? t + 1 : t;              // shared list: skip the run's own entry
+                o_rec[cp + t] = rec[off + pos];
+                if (o_tw) o_tw[cp + t] = tw[off + (sp != DESC_SP_NONE ? sp : pos)];
             }
         }
     }
@@ -2630,7 +2915,7 @@ __global__ __launch_bounds__(256) void k_export_plan(OwnerArgs a) {
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_slots; i += (int64_t)gridDim.x * 256) {
         const uint64_t d = a.run_desc[i];
-        const uint32_t len = (uint32_t)(d & 0xFFull);
+        const uint32_t len = desc_pairs(d);
         if (len) atomicAdd(&s_tot[owner_of(a, a.run_x[i])], (1ull << EXP_REC_BITS) | len);
     }
     __syncthreads();
@@ -2646,7 +2931,7 @@ __global__ __launch_bounds__(256) void k_export_fill(OwnerArgs a) {
     __shared__ unsigned long long s_rr[MAX_OWNERS];      // runs << 32 | records of this chunk per owner
     __shared__ unsigned long long s_rbase[MAX_OWNERS], s_cbase[MAX_OWNERS];
     __shared__ uint64_t s_src[EXP_CHUNK], s_dst[EXP_CHUNK];
-    __shared__ uint8_t s_len[EXP_CHUNK];
+    __shared__ uint8_t s_len[EXP_CHUNK], s_sp[EXP_CHUNK];
     const int64_t n_chunks = (a.n_slots + EXP_CHUNK - 1) / EXP_CHUNK;
     for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
         if (threadIdx.x < MAX_OWNERS) s_rr[threadIdx.x] = 0;
@@ -2659,11 +2944,11 @@ __global__ __launch_bounds__(256) void k_export_fill(OwnerArgs a) {
             const int64_t i = ch * EXP_CHUNK + (int64_t)u * 256 + threadIdx.x;
             d[u] = i < a.n_slots ? a.run_desc[i] : 0ull;
             x[u] = 0; o[u] = 0; my_run[u] = my_rec[u] = 0;
-            if (d[u] & 0xFFull) x[u] = a.run_x[i];
+            if (desc_len(d[u])) x[u] = a.run_x[i];
         }
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const uint32_t len = (uint32_t)(d[u] & 0xFFull);
+            const uint32_t len = desc_pairs(d[u]);
             if (len) {
                 o[u] = owner_of(a, x[u]);
                 const unsigned long long old = atomicAdd(&s_rr[o[u]], (1ull << 32) | len);
@@ -2687,13 +2972,14 @@ __global__ __launch_bounds__(256) void k_export_fill(OwnerArgs a) {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int r = u * 256 + threadIdx.x;
-            const uint32_t len = (uint32_t)(d[u] & 0xFFull);
+            const uint32_t len = desc_pairs(d[u]);                   // exported runs are private rows: pairs only
             s_len[r] = (uint8_t)len;
+            s_sp[r] = (uint8_t)desc_sp(d[u]);
             if (len) {
                 const uint64_t rp = a.run_base[o[u]] + s_rbase[o[u]] + my_run[u];
                 const uint64_t cp = a.rec_base[o[u]] + s_cbase[o[u]] + my_rec[u];
                 *reinterpret_cast<uint2*>(&a.o_hdr[2 * rp]) = make_uint2(x[u], len);
-                s_src[r] = d[u] >> 8;
+                s_src[r] = desc_slot(d[u]);
                 s_dst[r] = cp;
             }
         }
@@ -2705,9 +2991,11 @@ __global__ __launch_bounds__(256) void k_export_fill(OwnerArgs a) {
             bool ok[CU];
 #pragma unroll
             for (int u = 0; u < CU; ++u) {
+                const uint32_t sp = s_sp[r0 + u];
+                const uint32_t pos = (uint32_t)l >= sp ? l + 1 : l;     // shared list: skip the run's own entry
                 ok[u] = (uint32_t)l < (uint32_t)s_len[r0 + u];
-                v[u] = ok[u] ? a.rec[s_src[r0 + u] + l] : 0u;
-                w[u] = (ok[u] && a.o_tw) ? a.tw[s_src[r0 + u] + l] : 0u;
+                v[u] = ok[u] ? a.rec[s_src[r0 + u] + pos] : 0u;
+                w[u] = (ok[u] && a.o_tw) ? a.tw[s_src[r0 + u] + (sp != DESC_SP_NONE ? sp : pos)] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < CU; ++u) {
@@ -2730,7 +3018,7 @@ __global__ void k_import(const uint32_t* hdr, int64_t n_runs, const uint64_t* re
                          uint64_t run_base, uint32_t* run_x, uint64_t* run_desc) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += (int64_t)gridDim.x * blockDim.x) {
         run_x[run_base + i] = hdr[2 * i + 1] ? hdr[2 * i] : RUN_X_EMPTY;
-        run_desc[run_base + i] = ((rec_base + rec_pos[i]) << 8) | (uint64_t)hdr[2 * i + 1];
+        run_desc[run_base + i] = make_desc(rec_base + rec_pos[i], hdr[2 * i + 1]);
     }
 }
 
@@ -2751,7 +3039,7 @@ struct otto_covis_ctx {
     // chunk scratch
     DevBuf pair_base, ev_base, partial, cls_pos[N_WIN_CLASSES], sess_list, cls_byte;
     int fast_path = 1;
-    int fused = 1;                 // k_expand_fused when no filter kind is configured
+    int fused = 2;                 // no filter kind configured: 2 = k_expand_lists (component lists), 1 = k_expand_fused, 0 = class-sorted kernels
     // index
     bool index_valid = false;
     DevBuf cnt64, run_start, run_rank, sorted_desc, item_start, boost, flag, counters;
@@ -2883,8 +3171,10 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
         OTTO_HIP(hipMemcpyAsync(&tot[0], c->pair_base.as<uint64_t>() + n_sess, 8, hipMemcpyDeviceToHost, s));
         OTTO_HIP(hipMemcpyAsync(&tot[1], c->ev_base.as<uint64_t>() + n_sess, 8, hipMemcpyDeviceToHost, s));
         OTTO_HIP(hipStreamSynchronize(s));
-        const uint64_t n_slots = tot[0], n_ev = tot[1];
-        OTTO_REQUIRE(c->rec_used + n_slots < (1ull << 55), "record slot space exhausted");
+        const uint64_t n_ev = tot[1];
+        const bool lists = c->fused == 2;                  // component lists: n list slots per window behind the pair slots
+        const uint64_t n_slots = tot[0] + (lists ? n_ev : 0ull);
+        OTTO_REQUIRE(c->rec_used + n_slots < (1ull << DESC_SLOT_BITS), "record slot space exhausted");
         OTTO_TRY(c->rec.ensure((size_t)(c->rec_used + n_slots) * 4, (size_t)c->rec_used * 4, s));
         if (p.want_time) OTTO_TRY(c->tw.ensure((size_t)(c->rec_used + n_slots) * 4, (size_t)c->rec_used * 4, s));
         OTTO_TRY(c->run_x.ensure((size_t)(c->run_used + n_ev) * 4, (size_t)c->run_used * 4, s));
@@ -2897,6 +3187,7 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
         a.rec = c->rec.as<uint32_t>(); a.tw = c->tw.as<uint32_t>();
         a.run_x = c->run_x.as<uint32_t>(); a.run_desc = c->run_desc.as<uint64_t>();
         a.rec_base = c->rec_used; a.run_base = c->run_used;
+        a.list_base = c->rec_used + tot[0];
         a.window = p.window; a.max_gap = p.max_gap;
         a.t0 = p.ts_min; a.tspan = (int64_t)p.ts_max - (int64_t)p.ts_min;
         a.debug = c->debug_skip >> 4;
@@ -2905,12 +3196,21 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
         int per_cu = 0, n_cu = 0, dev = 0;
         OTTO_HIP(hipGetDevice(&dev));
         OTTO_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        if (p.want_time) OTTO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_expand_fused<true, false>, 256, 0));
+        if (lists) {
+            if (p.want_time) OTTO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_expand_lists<true, false>, 256, 0));
+            else OTTO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_expand_lists<false, false>, 256, 0));
+        } else if (p.want_time) OTTO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_expand_fused<true, false>, 256, 0));
         else OTTO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_expand_fused<false, false>, 256, 0));
         const int64_t resident = (int64_t)(per_cu > 0 ? per_cu : 4) * (n_cu > 0 ? n_cu : 256);   // one round of resident workgroups
         const int grid = (int)(blocks < resident ? blocks : resident);
-        kname(c, OTTO_COVIS_T_EXPAND, "k_expand_fused<%s>", p.want_time ? "true" : "false");
-        if (a.debug) {
+        kname(c, OTTO_COVIS_T_EXPAND, lists ? "k_expand_lists<%s>" : "k_expand_fused<%s>", p.want_time ? "true" : "false");
+        if (lists) {
+            if (a.debug) {
+                if (p.want_time) k_expand_lists<true, true><<<grid, 256, 0, s>>>(a, n_sess);
+                else k_expand_lists<false, true><<<grid, 256, 0, s>>>(a, n_sess);
+            } else if (p.want_time) k_expand_lists<true, false><<<grid, 256, 0, s>>>(a, n_sess);
+            else k_expand_lists<false, false><<<grid, 256, 0, s>>>(a, n_sess);
+        } else if (a.debug) {
             if (p.want_time) k_expand_fused<true, true><<<grid, 256, 0, s>>>(a, n_sess, c->fast_path);
             else k_expand_fused<false, true><<<grid, 256, 0, s>>>(a, n_sess, c->fast_path);
         } else if (p.want_time) k_expand_fused<true, false><<<grid, 256, 0, s>>>(a, n_sess, c->fast_path);
@@ -2941,7 +3241,7 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
         OTTO_HIP(hipMemcpyAsync(&totals[2 + cl], c->cls_pos[cl].as<uint64_t>() + n_sess, 8, hipMemcpyDeviceToHost, s));
     OTTO_HIP(hipStreamSynchronize(s));
     const uint64_t n_slots = totals[0], n_ev = totals[1];
-    OTTO_REQUIRE(c->rec_used + n_slots < (1ull << 55), "record slot space exhausted");
+    OTTO_REQUIRE(c->rec_used + n_slots < (1ull << DESC_SLOT_BITS), "record slot space exhausted");
 
     OTTO_TRY(c->rec.ensure((size_t)(c->rec_used + n_slots) * 4, (size_t)c->rec_used * 4, s));
     if (p.want_time) OTTO_TRY(c->tw.ensure((size_t)(c->rec_used + n_slots) * 4, (size_t)c->rec_used * 4, s));
@@ -3440,7 +3740,7 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
     if (strcmp(name, "packed_heavy") == 0) { c->packed_heavy = value == 2 ? 2 : (value != 0); c->index_valid = false; return 0; }
     if (strcmp(name, "bucket_index") == 0) { c->bucket_index = value != 0; return 0; }
     if (strcmp(name, "guess") == 0) { c->guess = value != 0; return 0; }           // threshold guessing on/off (A/B)
-    if (strcmp(name, "fused") == 0) { c->fused = value != 0; return 0; }           // fused in-order expansion on/off (A/B)
+    if (strcmp(name, "fused") == 0) { c->fused = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return 0; }   // 2 component lists, 1 fused register rows, 0 class-sorted kernels (A/B)
     if (strcmp(name, "fast_path") == 0) { c->fast_path = value != 0; return 0; }   // gap-free window kernel on/off (A/B)
     if (strcmp(name, "part_sized") == 0) { c->part_sized = value != 0; return 0; }   // A/B: counted buckets only
     if (strcmp(name, "partition") == 0) {

@@ -62,14 +62,16 @@ def test_product_spec_matches_oracle_spec():
     assert cs.ALL_KINDS == co.ALL_KINDS and cs.Q16 == co.Q16
 
 
-@pytest.mark.parametrize('kinds', [cs.ALL_KINDS, ('time_weighted', 'click_weighted'), ('cart_weighted',)],
-                         ids=['filters-class-kernels', 'fused-time', 'fused'])
-def test_pair_expand_records_match_oracle(gpu_device, kinds):
-    """K1 alone: every window's runs/records equal the oracle's per-window expansion (runs in event order; the
-    records of one run are a set -- their order inside the run carries no meaning and differs between the
-    class-sorted kernels and the fused register kernel)."""
+@pytest.mark.parametrize('kinds,options', [(cs.ALL_KINDS, None), (('time_weighted', 'click_weighted'), None), (('cart_weighted',), None),
+                                           (('time_weighted', 'click_weighted'), {'fused': 1}), (('cart_weighted',), {'fused': 1})],
+                         ids=['filters-class-kernels', 'lists-time', 'lists', 'fused-rows-time', 'fused-rows'])
+def test_pair_expand_records_match_oracle(gpu_device, kinds, options):
+    """K1 alone: every window's records equal the oracle's per-window expansion. A run is (aid_x, a list of records);
+    a run descriptor with sp != 63 points at a SHARED component list that holds the run's own aid at position sp (not a
+    pair; its slot of the time channel carries the run's time extra). The records of a window are compared as a set of
+    (x, y, type_y, filter bits, time extra): each ordered pair at most once, whatever runs it is spread over."""
     ev = generate_sessions(1500, n_aids=400, seed=3)
-    b, _ = _build(ev, gpu_device, kinds=kinds)
+    b, _ = _build(ev, gpu_device, kinds=kinds, options=options)
     rec, tw, run_x, run_desc = b.copy_records()
     sp = co.CovisSpec()
     t0, t1 = int(ev.ts.min()), int(ev.ts.max())
@@ -78,30 +80,42 @@ def test_pair_expand_records_match_oracle(gpu_device, kinds):
     nwin = np.where(np.minimum(L, 30) >= 2, np.minimum(L, 30), 0)
     ev_base = np.r_[0, np.cumsum(nwin)]
     pair_base = np.r_[0, np.cumsum(nwin * (nwin - 1))]
-    assert b.stats()['tail_events'] == ev_base[-1] and b.stats()['pair_slots'] == pair_base[-1]
-    total = 0
+    lists = len(rec) == pair_base[-1] + ev_base[-1]          # component lists: n list slots per window behind the pair slots
+    assert b.stats()['tail_events'] == ev_base[-1] and b.stats()['pair_slots'] == pair_base[-1] + (ev_base[-1] if lists else 0)
+    total = shared_runs = 0
     for s in range(ev.n_sessions):
         want = co.expand_window_python(ev.aid, ev.ts, ev.type, int(ev.sess_off[s]), int(ev.sess_off[s + 1]), sp, fk, t0, t1)
         got = []
         used = set()
         for r in range(int(ev_base[s]), int(ev_base[s + 1])):
             d = int(run_desc[r])
-            ln, off = d & 0xFF, d >> 8
-            if ln:
+            ln, off, spos = d & 0x3F, (d >> 8) & ((1 << 40) - 1), (d >> 48) & 63
+            if not ln:
+                assert d == 0 and run_x[r] == 0xFFFFFFFF
+                continue
+            x = int(run_x[r])
+            if spos != 63:
+                assert lists and pair_base[-1] + ev_base[s] <= off and off + ln <= pair_base[-1] + ev_base[s + 1]
+                assert spos < ln and int(rec[off + spos]) & 0x3FFFFFF == x
+                shared_runs += 1
+            else:
                 assert pair_base[s] <= off and off + ln <= pair_base[s + 1]
-            run = []
             for t in range(ln):
+                if t == spos:
+                    continue
                 rc = int(rec[off + t])
-                assert off + t not in used
-                used.add(off + t)
-                run.append((int(run_x[r]), rc & 0x3FFFFFF, (rc >> 26) & 3, rc >> 28, int(tw[off + t]) if tw is not None else 0))
-            got += sorted(run)
+                if spos == 63:
+                    assert off + t not in used
+                    used.add(off + t)
+                e = 0 if tw is None else int(tw[off + (spos if spos != 63 else t)])
+                got.append((x, rc & 0x3FFFFFF, (rc >> 26) & 3, rc >> 28, e))
         if tw is None:
             want = [w[:4] + (0,) for w in want]
-        want = [w for _, grp in itertools.groupby(want, key=lambda w: w[0]) for w in sorted(grp)]
-        assert got == want, f'session {s}'
+        assert len(set(g[:2] for g in got)) == len(got), f'session {s}: a pair occurs twice'
+        assert sorted(got) == sorted(want), f'session {s}'
         total += len(want)
     assert b.stats()['pairs'] == total
+    assert (shared_runs > 0) == lists
 
 
 @pytest.mark.parametrize('kinds', [cs.ALL_KINDS, NOFILT], ids=['all-kinds', 'fused'])
@@ -117,8 +131,8 @@ def test_topk_all_kinds_match_oracle(gpu_device, n_sessions, n_aids, seed, kinds
     assert b.stats()['pairs'] == st['P']
 
 
-@pytest.mark.parametrize('options', [{'fast_path': 0}, {'fused': 0}, {'fused': 0, 'fast_path': 0}],
-                         ids=['fused-general-only', 'class-kernels', 'class-kernels-general-only'])
+@pytest.mark.parametrize('options', [{'fused': 1}, {'fused': 1, 'fast_path': 0}, {'fused': 0}, {'fused': 0, 'fast_path': 0}],
+                         ids=['fused-rows', 'fused-rows-general-only', 'class-kernels', 'class-kernels-general-only'])
 def test_expand_variants_agree(gpu_device, options):
     """The fused K1 with its gap-free shortcut switched off (every window through the general row loop), and the
     class-sorted kernels forced for the same kinds, give the oracle's rows too."""
