@@ -665,12 +665,15 @@ __device__ __forceinline__ void expand_task_lists(const ExpandArgs& a, uint4* ev
     wave_lds_sync();
     uint32_t same = 0;                                          // window-relative bits: events holding my aid
     if (!(DBG && (a.debug & 4))) {
-        for (int j0 = 0; j0 < nmax4; j0 += 4) {
+        // from the last event down: the compare result is shifted in as the carry of same + same, two VALU
+        // instructions per event (compare, add-with-carry) instead of compare / select / shift-or
+        for (int j0 = nmax4 - 4; j0 >= 0; j0 -= 4) {
             uint32_t ax[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) ax[u] = evw[(j0 + u) & (G - 1)].x;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) same |= (ax[u] == aid ? 1u : 0u) << ((j0 + u) & 31);
+            for (int u = 3; u >= 0; --u)
+                asm volatile("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(same) : "v"(ax[u]), "v"(aid) : "vcc");
         }
     } else same = 1u << g;
     same &= n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
@@ -811,7 +814,7 @@ __device__ __forceinline__ void expand_task_lists(const ExpandArgs& a, uint4* ev
 // One launch over the sessions in memory order (as k_expand_fused): 64 sessions per wave round, sorted with ballots
 // into three window size classes (n <= 8 / 16 / 32 -> 8 / 16 / 32 lanes per window) in a wave-private LDS task list.
 template <bool TIME, bool DBG>
-__global__ __launch_bounds__(256) void k_expand_lists(ExpandArgs a, int64_t n_sess) {
+__global__ __launch_bounds__(256, 4) void k_expand_lists(ExpandArgs a, int64_t n_sess) {
     __shared__ uint4 s_ev[4][64];
     __shared__ uint4 s_ta[4][64];       // task: wstart lo, wstart hi | n << 16, pair_base lo, hi
     __shared__ uint2 s_tb[4][64];       //       ev_base lo, hi

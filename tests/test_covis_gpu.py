@@ -457,13 +457,14 @@ BENCH_KINDS = ('click_weighted', 'cart_weighted', 'order_weighted')
 
 def test_full_otto_bench_path_bit_exact_and_sampled_oracle(gpu_device, full_otto):
     """The configuration ``bench.py`` times, at the size it times it (BASELINE.json configs[1]: 14,571,582 sessions,
-    ~243 M events, 1,855,603 aids, the three type-weighted kinds, top-20), through the DEFAULT options: fused register
-    pair-expand (`k_expand_fused<false>`, gap-free shortcut on), bucketed index, packed heavy-aid layouts, threshold
-    guessing. Two checks:
+    ~243 M events, 1,855,603 aids, the three type-weighted kinds, top-20), through the DEFAULT options: component-list
+    pair-expand (`k_expand_lists<false>`: shared lists, one run per (aid, component)), bucketed index, packed heavy-aid
+    layouts, threshold guessing. Checks:
 
     1. bit for bit against a run that shares none of those code paths: 7 session chunks, class-sorted pair-expand
        kernels (`fused` 0, `fast_path` 0), global-atomic index (`bucket_index` 0), wide heavy-aid tables
-       (`packed_heavy` 0), two-pass top-k (`guess` 0);
+       (`packed_heavy` 0), two-pass top-k (`guess` 0); and against the register-row pair-expand of round 2 (`fused` 1,
+       one private row per aid and window: one run per distinct aid of a window);
     2. a SAMPLED ORACLE check: ~2,000 `aid_x` stratified over the three size bins of the reduce (the five heaviest aids,
        100 of the heaviest 3 % ~ L bin, 500 of the next 26 % ~ M bin, 1,400 of the rest ~ S bin). The row of `aid_x`
        depends only on the sessions that hold `aid_x`, so the oracle run on exactly those sessions must reproduce the
@@ -475,9 +476,14 @@ def test_full_otto_bench_path_bit_exact_and_sampled_oracle(gpu_device, full_otto
     assert st1['pairs'] > 1_000_000_000 and st1['items_l'] > 0 and st1['items_m'] > 0 and st1['items_s'] > 0
     assert st1['retries'] == 0
     out2, st2 = _full_run(d, dev, BENCH_KINDS, k, 7, {'fused': 0, 'fast_path': 0, 'bucket_index': 0, 'packed_heavy': 0, 'guess': 0})
-    assert st1['pairs'] == st2['pairs'] and st1['runs'] == st2['runs']
+    # an aid has one run per COMPONENT of a window with the lists, one per window with private rows
+    assert st1['pairs'] == st2['pairs'] and st2['runs'] <= st1['runs'] <= 1.1 * st2['runs']
     _assert_outputs_identical(out1, out2, BENCH_KINDS, k, dev)
     del out2
+    out3, st3 = _full_run(d, dev, BENCH_KINDS, k, 1, {'fused': 1})
+    assert st3['pairs'] == st2['pairs'] and st3['runs'] == st2['runs'] and st3['pair_slots'] < st1['pair_slots']
+    _assert_outputs_identical(out1, out3, BENCH_KINDS, k, dev)
+    del out3
     _assert_list_properties(out1, BENCH_KINDS, k, dev, OTTO_N_AIDS)
     # cart_weighted (1,9,6) dominates click_weighted (1,6,3) pair by pair, so its best weight per aid is >= too
     some = out1['click_weighted'][2] > 0
