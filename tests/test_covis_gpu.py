@@ -131,6 +131,58 @@ def test_topk_all_kinds_match_oracle(gpu_device, n_sessions, n_aids, seed, kinds
     assert b.stats()['pairs'] == st['P']
 
 
+def _hub_events(n_hub_sessions, per_session, repeated, n_aids, hub_type=0):
+    """Sessions `hub, a, b, c, ...` (clicks, fresh aids every session, seconds apart) plus `repeated` partners that meet
+    the hub in two sessions each: the hub has n_hub_sessions * per_session keys of ONE click record and `repeated` keys of
+    two records."""
+    aid, typ, off = [], [], [0]
+    nxt = 1 + repeated
+    for s in range(n_hub_sessions):
+        row = [0] + list(range(nxt, nxt + per_session))
+        nxt += per_session
+        if s < 2 * repeated:
+            row.append(1 + s // 2)
+        aid += row
+        typ += [hub_type] + [0] * (len(row) - 1)
+        off.append(len(aid))
+    assert nxt <= n_aids
+    ts = (1_660_000_000 + np.arange(len(aid))).astype(np.int32)
+    return Events(aid=np.array(aid, dtype=np.uint32), ts=ts, type=np.array(typ, dtype=np.uint8),
+                  sess_off=np.array(off, dtype=np.int64), n_aids=n_aids)
+
+
+@pytest.mark.parametrize('n_hub,per,repeated', [(40, 28, 5), (40, 28, 25), (300, 28, 7), (300, 28, 40)],
+                         ids=['M-5-heavy', 'M-25-heavy', 'L-7-heavy', 'L-40-heavy'])
+def test_topk_walks_with_fewer_heavy_keys_than_k(gpu_device, n_hub, per, repeated):
+    """The multi-wave bins rank the keys of more than one click record first and fall back to every key when fewer
+    than k of them exist: a hub aid of the M bin (1,120 records) / the L bin (8,400 records: partitions, merge) whose
+    partners are almost all single clicks, with fewer and with more than k = 20 repeated partners; the hub's light
+    keys tie on weight, so the rows below the repeated partners are the smallest aid_y."""
+    ev = _hub_events(n_hub, per, repeated, n_aids=1 + repeated + n_hub * per + 5)
+    kinds = ('click_weighted', 'cart_weighted', 'order_weighted')
+    want = _oracle_rows(ev, kinds)
+    for options in (None, {'hot': 0}):
+        b, got = _build(ev, gpu_device, kinds=kinds, options=options)
+        _assert_rows_equal(got, want, kinds)
+    st = b.stats()
+    assert st['items_m'] + st['items_l'] >= 1
+
+
+def test_topk_type_weights_that_rank_a_single_click_above_other_keys(gpu_device, monkeypatch):
+    """Type weights (5, 1, 2): one click record outweighs two cart records, so "more than one click record" says
+    nothing about the rank of a key -- the heavy-first walks must switch themselves off (`hot_ok` on the host)."""
+    w = {'click_weighted': (5, 1, 2), 'cart_weighted': (1, 9, 6), 'order_weighted': (3, 3, 1)}
+    for mod in (cs, co):
+        monkeypatch.setattr(mod, 'TYPE_WEIGHTS', {**mod.TYPE_WEIGHTS, **w})
+    import otto_amd.covisitation.engine as eng
+    monkeypatch.setattr(eng, 'TYPE_WEIGHTS', cs.TYPE_WEIGHTS)
+    kinds = ('click_weighted', 'cart_weighted', 'order_weighted')
+    ev = generate_sessions(20000, n_aids=60, seed=21)
+    want = _oracle_rows(ev, kinds)
+    _, got = _build(ev, gpu_device, kinds=kinds)
+    _assert_rows_equal(got, want, kinds)
+
+
 @pytest.mark.parametrize('options', [{'fused': 1}, {'fused': 1, 'fast_path': 0}, {'fused': 0}, {'fused': 0, 'fast_path': 0}],
                          ids=['fused-rows', 'fused-rows-general-only', 'class-kernels', 'class-kernels-general-only'])
 def test_expand_variants_agree(gpu_device, options):
