@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the hot path (BASELINE.json metric).
 
-`python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.
+`python bench.py --gpus N --steps K --warmup W`. N > 1 runs one process per GPU: either the driver launches them
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: WORLD_SIZE is set and this process is
+one rank), or a plain `python bench.py --gpus N` starts them itself -- from a parent that never touches the GPU -- and
+relays rank 0's JSON line.
 
 A "step" is one full covisitation build over one batch of synthetic OTTO-shape
 sessions that are already resident in HBM: pair-expand -> inverted index ->
@@ -54,10 +56,14 @@ def parse():
 def algorithmic_bytes(st, k, nk):
     """Algorithmic HBM bytes per launch of each kernel (DESIGN.md 'Measurement')."""
     S, Et, P = st['sessions'], st['tail_events'], st['pairs']
+    # pair-expand: read aid 4 + ts 4 + type 1 per window event, 3 x 8 B per session (CSR offset + two slot bases); write one
+    # (aid_x u32, descriptor u64) per window event and the records: with the component lists (k_expand_lists) one 4-byte
+    # list word per run that reads a shared list + the records of the private rows; one 4-byte record per PAIR with the
+    # round-2 layout ('expand_rows': the bytes SURVEY.md section 8 d prices, kept for comparison)
+    words = st.get('shared_runs', 0) + st.get('row_records', 0)
     out = {
-        # read aid 4 + ts 4 + type 1 per window event, 3 x 8 B per session (CSR offset + two slot bases);
-        # write one 4-byte record per pair and one (aid_x u32, descriptor u64) per window event
-        'expand': 9 * Et + 24 * S + 4 * P + 12 * Et,
+        'expand': 9 * Et + 24 * S + 4 * (words if st.get('shared_runs', 0) else P) + 12 * Et,
+        'expand_rows': 9 * Et + 24 * S + 4 * P + 12 * Et,
     }
     # index: read (aid_x u32, descriptor u64) per window event once, write one descriptor per run grouped by aid_x (the
     # bucket split's intermediate copy and the second reads are overhead, not algorithmic)
@@ -73,7 +79,7 @@ def algorithmic_bytes(st, k, nk):
     return out
 
 
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'round2', 'traffic.json')
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'round3', 'traffic.json')
 
 
 def source_hash():
@@ -174,7 +180,8 @@ def dropin_leg(data, dev, n_aids, ts_min, ts_max, k, reps=2):
 
 
 def cpu_baseline(dev_data, n_sessions, k):
-    """Time the CPU restatement (oracle/, kind 'port') on the first n_sessions of the same stream."""
+    """Time the CPU restatement (oracle/, kind 'port') on the first n_sessions of the same stream: the best of a few
+    thread counts (an all-core run can lose to a quarter of the cores on a 256-thread host; every run is reported)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import numpy as np
     off = dev_data['sess_off'][:n_sessions + 1].cpu().numpy()
@@ -187,10 +194,15 @@ def cpu_baseline(dev_data, n_sessions, k):
     except Exception:
         coc = None
     if coc is not None and coc.available():
-        cores = os.cpu_count() or 1                      # every host core
-        r = coc.covis_topk_c(aid, ts, typ, off, dev_data['n_aids'], BENCH_KINDS, k=k, threads=cores, rows=False)
-        pairs, dt = r['P'], r['seconds_in_c']
-        impl = f'oracle/covis_oracle.c (gcc -O3, OpenMP, {cores} threads)'
+        host = os.cpu_count() or 1
+        tried = {}
+        for cores_try in sorted({min(host, 64), min(host, 128), host}):
+            r = coc.covis_topk_c(aid, ts, typ, off, dev_data['n_aids'], BENCH_KINDS, k=k, threads=cores_try, rows=False)
+            tried[cores_try] = (r['P'], r['seconds_in_c'])
+        cores = min(tried, key=lambda c_: tried[c_][1])
+        pairs, dt = tried[cores]
+        impl = (f'oracle/covis_oracle.c (gcc -O3, OpenMP), best of threads '
+                + ', '.join(f'{c_}: {tried[c_][0] / tried[c_][1]:.3g} pairs/s' for c_ in sorted(tried)))
     else:
         import covis_oracle as co
         cores = 1
@@ -235,6 +247,20 @@ def mf_cpu_baseline(U, V, users, items, n_items, sample):
 
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks with torch.distributed.run (one process per GPU,
+    rendezvous on 127.0.0.1) from THIS process, which has made no GPU call (torch is not even imported here), pass
+    their output through and return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     a = parse()
     import torch
@@ -244,6 +270,8 @@ def main():
     from otto_amd.covisitation.distributed import ShardedCovisBuilder, global_ts_range
     from otto_amd import _lib
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(a.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -273,7 +301,9 @@ def main():
         del full
         torch.cuda.empty_cache()
     else:
-        data = generate_sessions_torch(a.sessions, n_aids=OTTO_N_AIDS, seed=42 + rank, device=dev)
+        # weak scaling: every rank draws its own sessions (seed 42 + rank) from ONE aid popularity table (rank 0's), as the
+        # shards of one stream would -- rank 0 of N ranks is exactly the N = 1 workload
+        data = generate_sessions_torch(a.sessions, n_aids=OTTO_N_AIDS, seed=42 + rank, device=dev, pop_seed=42)
     n_aids = data['n_aids']
     if world > 1:
         ts_min, ts_max = global_ts_range(data['ts'].cpu() if stage else data['ts'])
@@ -340,7 +370,7 @@ def main():
         # the traffic file is keyed by rocprofv3's kernel names: exact instantiations where a slot is one template, prefixes
         # for the index / partition slots (several small kernels)
         ksub = {slot: tuple(n for n in names.split(' + ') if '<' in n and '/' not in n and '*' not in n) for slot, names in knames.items()}
-        ksub['index'] = ('k_bkt_split', 'k_bkt_local')
+        ksub['index'] = ('k_bkt_split', 'k_bkt_fused')
         ksub['partition'] = ('k_partition',)
         result = {
             'metric': 'aid-pairs/sec covisitation build',
@@ -362,7 +392,11 @@ def main():
                 'parallelism': 'single GPU' if world == 1 else f'session-chunk x{world}, RCCL all-to-all-v of expanded runs by aid_x owner',
             },
             'roofline': roofline_obj(knames[dom], cand[dom], ab[dom], pmc_traffic(ksub[dom], full_otto)),
-            'roofline_expand': roofline_obj(knames['expand'], cand['expand'], ab['expand'], pmc_traffic(ksub['expand'], full_otto)),
+            'roofline_expand': {**roofline_obj(knames['expand'], cand['expand'], ab['expand'], pmc_traffic(ksub['expand'], full_otto)),
+                                'frac_on_round2_bytes': round(ab['expand_rows'] / (cand['expand'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if cand['expand'] > 0 else None,
+                                'round2_algorithmic_bytes': int(ab['expand_rows']),
+                                'note': 'algorithmic_bytes = what the component-list layout moves (one list word per run + private rows); '
+                                        'frac_on_round2_bytes prices the same time on the one-record-per-pair bytes of SURVEY.md section 8 d'},
             'kernel_ms': {k_: round(v, 3) for k_, v in kernel_ms.items()},
             'stats': st,
         }

@@ -23,7 +23,7 @@ def run(a, dev, rank, world, cpu_baseline_fn=None, traffic_fn=None):
     from otto_amd.matrix_factorization.bpr import ItemTableSync
     d = a.mf_factors
     n_users, n_items = (OTTO_N_SESSIONS if a.sessions >= OTTO_N_SESSIONS else a.sessions), OTTO_N_AIDS
-    data = generate_sessions_torch(n_users, n_aids=n_items, seed=142 + rank, device=dev)
+    data = generate_sessions_torch(n_users, n_aids=n_items, seed=142 + rank, device=dev, pop_seed=142)   # one item catalogue on every rank
     E = data['aid'].numel()
     rows = min(a.mf_rows if a.scaling == 'weak' else a.mf_rows // world, E)
     lens = data['sess_off'][1:] - data['sess_off'][:-1]
@@ -39,23 +39,24 @@ def run(a, dev, rank, world, cpu_baseline_fn=None, traffic_fn=None):
     sync = ItemTableSync(V) if world > 1 else None
     eng = MFEngine(n_users, n_items, d, ROWS_PER_LAUNCH, device=dev)
     n_launch = (rows + ROWS_PER_LAUNCH - 1) // ROWS_PER_LAUNCH
+    n_slots = sync.global_max(n_launch) if sync is not None else n_launch   # one exchange schedule for all ranks
     loss = torch.zeros(n_launch, device=dev)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(n_launch)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n_launch)]
 
     def epoch(e, timed):
-        for q in range(n_launch):
-            lo, hi = q * ROWS_PER_LAUNCH, min(rows, (q + 1) * ROWS_PER_LAUNCH)
-            if timed:
-                ev0[q].record()
-            eng.bpr_step(U, V, users[lo:hi], items[lo:hi], 42, e, lo, 0.05, 0.0, BPR_HOGWILD, loss_sum=loss[q:q + 1])
-            if timed:
-                ev1[q].record()
-            if world > 1:
-                if hi - lo <= n_items // 4:          # few rows: worth tracking them for the sparse exchange (as bpr.train_epoch does)
-                    sync.touched(items[lo:hi])
-                if (q + 1) % SYNC_EVERY == 0 or q == n_launch - 1:
-                    sync.exchange()
+        for q in range(n_slots):
+            lo, hi = min(rows, q * ROWS_PER_LAUNCH), min(rows, (q + 1) * ROWS_PER_LAUNCH)
+            if hi > lo:
+                if timed:
+                    ev0[q].record()
+                eng.bpr_step(U, V, users[lo:hi], items[lo:hi], 42, e, lo, 0.05, 0.0, BPR_HOGWILD, loss_sum=loss[q:q + 1])
+                if timed:
+                    ev1[q].record()
+            if world > 1 and (q + 1) % SYNC_EVERY == 0:
+                sync.exchange()              # launches of 16.7 M rows are not tracked (ItemTableSync.tracking False): dense, asynchronous
+        if world > 1:
+            sync.finish()                    # drain: replicas bit-identical at the end of the epoch (as bpr.train_epoch does)
 
     def barrier():
         if world > 1:
@@ -153,4 +154,64 @@ def run(a, dev, rank, world, cpu_baseline_fn=None, traffic_fn=None):
         del Us, Vs
         if cpu_baseline_fn is not None:
             res['cpu_baseline'] = cpu_baseline_fn(U, V, users, items, n_items, 2_000_000)
+            res['rmf_sparse_adam']['cpu_baseline'] = rmf_cpu_baseline(users, items, tg, n_users, n_items + 1, dr, B)
+        # BASELINE config 5's trainer shape: the same hogwild epoch at d = 128
+        del U, V, eng
+        torch.cuda.empty_cache()
+        d2 = 128
+        U2 = (torch.randn(n_users, d2, device=dev, generator=g) * 0.1).contiguous()
+        V2 = (torch.randn(n_items, d2, device=dev, generator=g) * 0.1).contiguous()
+        eng2 = MFEngine(n_users, n_items, d2, ROWS_PER_LAUNCH, device=dev)
+        l2 = torch.zeros(1, device=dev)
+
+        def epoch128(e):
+            for q in range(n_launch):
+                lo, hi = q * ROWS_PER_LAUNCH, min(rows, (q + 1) * ROWS_PER_LAUNCH)
+                eng2.bpr_step(U2, V2, users[lo:hi], items[lo:hi], 42, e, lo, 0.05, 0.0, BPR_HOGWILD, loss_sum=l2)
+        epoch128(99)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for e in range(2):
+            epoch128(e)
+        e1.record()
+        torch.cuda.synchronize()
+        ms128 = e0.elapsed_time(e1) / 2
+        b128 = (16 + 6 * 4 * d2) * rows
+        res['d128'] = {'value': round(rows / (ms128 * 1e-3), 1), 'unit': 'triplets/s', 'ms_per_epoch': round(ms128, 3),
+                       'config': f'BPR-MF hogwild SGD, {n_users} x {n_items} x {d2}-d fp32, {rows} rows (BASELINE config 5 trainer shape, 1 GPU)',
+                       'roofline': {'kernel': 'k_bpr_hogwild', 'bound': 'hbm', 'achieved': round(b128 / (ms128 * 1e-3) / 1e9, 1),
+                                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(b128 / (ms128 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    'traffic': None, 'algorithmic_bytes': int(b128)}}
+        del U2, V2, eng2
     return res
+
+
+def rmf_cpu_baseline(users, items, target, n_users, n_items, d, B, n_batches=24):
+    """SURVEY.md section 8 d (2): the reference's own CPU path for a3 / a4 -- ``nn.Embedding(sparse=True)`` x 2, MSELoss,
+    ``SparseAdam`` (``src/matrix_factorization/torch_modules.py:8-19``, ``torch_trainer.py:59-78``) -- at the reference
+    config (32 factors, batch 262,144) on every host thread, >= 20 timed batches after 2 warm-up batches."""
+    import os
+    import torch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = min(n_batches + 2, users.numel() // B)
+    u, i, t = users[:n * B].cpu(), items[:n * B].cpu(), target[:n * B].cpu().float()
+    E1 = torch.nn.Embedding(n_users, d, sparse=True)
+    E2 = torch.nn.Embedding(n_items, d, sparse=True)
+    opt = torch.optim.SparseAdam(list(E1.parameters()) + list(E2.parameters()), lr=0.05)
+    crit = torch.nn.MSELoss()
+    t0 = 0.0
+    for b in range(n):
+        if b == 2:
+            t0 = time.perf_counter()
+        sl = slice(b * B, (b + 1) * B)
+        opt.zero_grad()
+        loss = crit((E1(u[sl]) * E2(i[sl])).sum(1), t[sl])
+        loss.backward()
+        opt.step()
+        loss.item()
+    dt = time.perf_counter() - t0
+    return {'value': round((n - 2) * B / dt, 1), 'unit': 'samples/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n - 2} batches of {B} of the same stream after 2 warm-up batches, torch {torch.__version__} CPU '
+                      f'nn.Embedding(sparse=True) + MSELoss + SparseAdam, {cores} threads, {dt:.2f} s'}

@@ -76,6 +76,8 @@ enum {
     OTTO_COVIS_STAT_RUNS_S,         /* runs gathered by the S / M / L size bins            */
     OTTO_COVIS_STAT_RUNS_M,
     OTTO_COVIS_STAT_RUNS_L,
+    OTTO_COVIS_STAT_SHARED_RUNS,    /* runs that read a shared component list (= list words the pair-expand wrote for them) */
+    OTTO_COVIS_STAT_ROW_RECORDS,    /* records the pair-expand wrote into private rows                                       */
     OTTO_COVIS_STAT_COUNT
 };
 

@@ -15,7 +15,7 @@ MAX_FILTERS = 4
 MAX_TYPE_WEIGHTS = 4
 GROUP_TYPE, GROUP_FILTER, GROUP_TIME = 0, 1, 2
 STAT_NAMES = ('sessions', 'tail_events', 'pair_slots', 'pairs', 'runs', 'items_s', 'items_m', 'items_l', 'retries',
-              'pairs_s', 'pairs_m', 'pairs_l', 'runs_s', 'runs_m', 'runs_l')
+              'pairs_s', 'pairs_m', 'pairs_l', 'runs_s', 'runs_m', 'runs_l', 'shared_runs', 'row_records')
 TIMING_NAMES = ('winscan', 'expand', 'index', 'partition', 'reduce_s', 'reduce_m', 'reduce_l', 'merge')
 
 

@@ -2542,11 +2542,12 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             constexpr int NITMAX = (RCAP + 63) / 64;
             uint32_t ent[NITMAX];
             uint32_t hv = 0, vv = 0;
+            const int nq = (int)((nocc + 63u) / 64u);                 // uniform in the wave
 #pragma unroll
             for (int q = 0; q < NITMAX; ++q) {
                 const uint32_t idx = (uint32_t)q * 64u + lane;
                 ent[q] = 0;
-                if (idx < nocc) {
+                if (q < nq && idx < nocc) {
                     const uint32_t sl = s_occ[NW > 1 ? wid * RCAP + idx : 0];
                     ent[q] = sl;
                     vv |= 1u << q;
@@ -2558,10 +2559,12 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             }
             uint32_t H = 0;
 #pragma unroll
-            for (int q = 0; q < NITMAX; ++q) H += (uint32_t)__popcll(__ballot((hv >> q) & 1u));
+            for (int q = 0; q < NITMAX; ++q)
+                if (q < nq) H += (uint32_t)__popcll(__ballot((hv >> q) & 1u));
             uint32_t hpos = 0, lpos = H;
 #pragma unroll
             for (int q = 0; q < NITMAX; ++q) {
+                if (q >= nq) break;
                 const bool v = (vv >> q) & 1u, h = (hv >> q) & 1u;
                 const uint64_t mh = __ballot(h), ml = __ballot(v && !h);
                 if (v) {
@@ -2638,7 +2641,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 for (uint32_t i = 0; i < n; ++i) {
                     K o;
                     kload(o, s_exw[j][i], s_exy[0][WIDE ? i : 0]);
-                    rank += kbetter(o, key) ? 1u : 0u;
+                    kcount_better(rank, o, key);
                 }
                 emit_ranked(j, key, rank, (int)n);
                 if (store_tau && n >= 32u && kvalid(key) && rank == 31u) ktau_store(key, a.tau_w, a.tau_y, (size_t)j * a.n_aids + x);
@@ -2686,7 +2689,74 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             //      guess; at least k per kind and no overflow: the ranked lists are the exact top-k ----
             bool fast_done = false;
             bool pre_issued = false;
-            bool gv = use_guess;
+            // ---- few heavy keys (the M bin: ~170 of an aid's ~600 keys): the wave of kind j selects ALONE from all of them --
+            //      its keys in registers (up to SHR per lane), lane-bests, k-th lane-best by counting = threshold, ballot-
+            //      compacted candidates, ranks by counting. One barrier instead of the four of P1 .. P4, no LDS atomics,
+            //      a third of their instructions.
+            constexpr bool SH = HOT && NW <= 4;
+            constexpr int SHR = 4;
+            if (SH && hot) {
+                __syncthreads();                             // s_hcnt of every wave
+                uint32_t pre[NW + 1];
+                pre[0] = 0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) pre[w + 1] = pre[w] + s_hcnt[NW > 1 ? w : 0];
+                const uint32_t th = pre[NW];
+                if (th < (uint32_t)a.k) {                    // fewer than k heavy keys: every key is walked
+                    hot = false;
+                    nwalk = nocc;
+                    nit = (int)((nwalk + 63u) / 64u);
+                } else if (th <= 64u * SHR) {
+                    if (wid < a.nk && wid < PKD) {
+                        const int j = wid;
+                        const uint32_t c0 = a.coef[j][0], c1 = a.coef[j][1], c2 = a.coef[j][2];
+                        K keys[SHR], lbk;
+                        kclear(lbk);
+#pragma unroll
+                        for (int q = 0; q < SHR; ++q) {
+                            const uint32_t e = (uint32_t)q * 64u + lane;
+                            kclear(keys[q]);
+                            if (e < th) {
+                                int w = 0;
+#pragma unroll
+                                for (int ww = 1; ww < NW; ++ww)
+                                    if (e >= pre[ww]) w = ww;
+                                const uint32_t sl = s_occ[NW > 1 ? w * RCAP + (int)(e - pre[w]) : 0];
+                                keys[q] = slot_key1((int)sl, c0, c1, c2);
+                                if (kbetter(keys[q], lbk)) lbk = keys[q];
+                            }
+                        }
+                        kstore(lbk, &s_exw[j][lane], &s_exy[0][WIDE ? lane : 0]);
+                        wave_lds_sync();
+                        uint32_t rank = 0;
+#pragma unroll 8
+                        for (int i = 0; i < 64; ++i) {
+                            K o;
+                            kload(o, s_exw[j][i], s_exy[0][WIDE ? i : 0]);
+                            kcount_better(rank, o, lbk);
+                        }
+                        const uint64_t mk = __ballot(kvalid(lbk) && rank == (uint32_t)(a.k - 1));
+                        K thr;
+                        kclear(thr);
+                        if (mk) thr = kshfl(lbk, __ffsll((unsigned long long)mk) - 1);
+                        wave_lds_sync();
+                        uint32_t n = 0;
+#pragma unroll
+                        for (int q = 0; q < SHR; ++q) {
+                            const bool c = kvalid(keys[q]) && !kbetter(thr, keys[q]);
+                            const uint64_t m = __ballot(c);
+                            const uint32_t pos = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            if (c && pos < (uint32_t)EXCAP) kstore(keys[q], &s_exw[j][pos], &s_exy[0][WIDE ? pos : 0]);
+                            n += (uint32_t)__popcll(m);
+                        }
+                        wave_lds_sync();
+                        if (n > (uint32_t)EXCAP) wave_exact_topk(j);
+                        else finish_list(j, n, false);
+                    }
+                    fast_done = true;
+                }
+            }
+            bool gv = use_guess && !fast_done;
 #pragma unroll
             for (int j = 0; j < PKD; ++j)
                 if (j < a.nk && !kvalid(guess[j])) gv = false;
@@ -2797,7 +2867,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                     for (int i = 0; i < 64; ++i) {
                         K o;
                         kload(o, s_exw[wid][i], s_exy[0][WIDE ? i : 0]);
-                        rank += kbetter(o, gb) ? 1u : 0u;
+                        kcount_better(rank, o, gb);
                     }
                     const uint64_t mk = __ballot(kvalid(gb) && rank == (uint32_t)(a.k - 1));
                     K thr;
@@ -3077,6 +3147,28 @@ __global__ __launch_bounds__(256) void k_export_fill(OwnerArgs a) {
     }
 }
 
+// statistics only (otto_covis_stats): runs that read a shared component list, records kept in private rows
+__global__ __launch_bounds__(256) void k_desc_totals(const uint64_t* run_desc, int64_t n_slots, unsigned long long* out) {
+    unsigned long long shared = 0, rows = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * 256) {
+        const uint64_t d = run_desc[i];
+        const uint32_t len = desc_len(d);
+        if (len) {
+            if (desc_sp(d) != DESC_SP_NONE) shared += 1;
+            else rows += len;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        shared += (unsigned long long)__shfl_xor((long long)shared, o, 64);
+        rows += (unsigned long long)__shfl_xor((long long)rows, o, 64);
+    }
+    if (lane_id() == 0) {
+        if (shared) atomicAdd(&out[0], shared);
+        if (rows) atomicAdd(&out[1], rows);
+    }
+}
+
 struct HdrLen {
     const uint32_t* hdr;
     __device__ uint64_t operator()(int64_t i) const { return hdr[2 * i + 1]; }
@@ -3102,6 +3194,8 @@ struct otto_covis_ctx {
     // K1 products
     DevBuf rec, tw, run_x, run_desc;
     uint64_t rec_used = 0;    // record slots
+    unsigned long long desc_totals[2] = {0, 0};   // statistics: shared-list runs, private-row records (otto_covis_stats)
+    bool desc_totals_valid = false;
     uint64_t run_used = 0;    // run slots
     int64_t sessions = 0;
     // chunk scratch
@@ -3209,6 +3303,7 @@ extern "C" int otto_covis_reset(otto_covis_ctx* c) {
     c->rec_used = c->run_used = 0;
     c->sessions = 0;
     c->index_valid = false;
+    c->desc_totals_valid = false;
     c->n_pairs = c->n_runs = 0;
     c->n_items[0] = c->n_items[1] = c->n_items[2] = 0;
     memset(c->ev_set, 0, sizeof c->ev_set);
@@ -3290,6 +3385,7 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
         c->run_used += n_ev;
         c->sessions += n_sess;
         c->index_valid = false;
+    c->desc_totals_valid = false;
         return 0;
     }
     // filter kinds: window classes (3 sizes x gap-free or not): one session list, six segments
@@ -3369,6 +3465,7 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
     c->run_used += n_ev;
     c->sessions += n_sess;
     c->index_valid = false;
+    c->desc_totals_valid = false;
     return 0;
 }
 
@@ -3814,6 +3911,7 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
         OTTO_REQUIRE(value >= 64 && value <= (1ll << 30), "l_cap out of range");
         c->l_cap = (uint32_t)value;
         c->index_valid = false;
+    c->desc_totals_valid = false;
         return 0;
     }
     if (strcmp(name, "debug_skip") == 0) { c->debug_skip = (int)value; return 0; }   // timing diagnostics, results invalid
@@ -3868,6 +3966,23 @@ extern "C" int otto_covis_stats(otto_covis_ctx* c, int64_t* out) {
     out[OTTO_COVIS_STAT_RUNS_S] = (int64_t)c->bin_runs[0];
     out[OTTO_COVIS_STAT_RUNS_M] = (int64_t)c->bin_runs[1];
     out[OTTO_COVIS_STAT_RUNS_L] = (int64_t)c->bin_runs[2];
+    // what the pair-expand kernel wrote: one list word per run that reads a shared list, the records of the private rows
+    if (!c->desc_totals_valid) {
+        c->desc_totals[0] = c->desc_totals[1] = 0;
+        if (c->run_used) {
+            OTTO_HIP(hipDeviceSynchronize());
+            OTTO_TRY(c->exp_totals.ensure(2 * MAX_OWNERS * 8, 0, nullptr));
+            OTTO_HIP(hipMemset(c->exp_totals.p, 0, 16));
+            const int64_t nb = ((int64_t)c->run_used + 255) / 256;
+            k_desc_totals<<<(unsigned)(nb < 4096 ? nb : 4096), 256>>>(c->run_desc.as<uint64_t>(), (int64_t)c->run_used, c->exp_totals.as<unsigned long long>());
+            OTTO_HIP(hipGetLastError());
+            OTTO_HIP(hipMemcpy(c->desc_totals, c->exp_totals.p, 16, hipMemcpyDeviceToHost));
+            c->exp_planned = 0;                       // the export cursors shared that buffer
+        }
+        c->desc_totals_valid = true;
+    }
+    out[OTTO_COVIS_STAT_SHARED_RUNS] = (int64_t)c->desc_totals[0];
+    out[OTTO_COVIS_STAT_ROW_RECORDS] = (int64_t)c->desc_totals[1];
     return 0;
 }
 
@@ -4050,5 +4165,6 @@ extern "C" int otto_covis_import_runs(otto_covis_ctx* c, const uint32_t* d_hdr, 
     c->rec_used += (uint64_t)n_recs;
     c->run_used += (uint64_t)n_runs;
     c->index_valid = false;
+    c->desc_totals_valid = false;
     return 0;
 }

@@ -52,6 +52,13 @@ __device__ __forceinline__ void kstore(KeyW k, uint64_t* w, uint32_t* y) { *w = 
 __device__ __forceinline__ void kload(KeyN& k, uint64_t w, uint32_t) { k.c = w; }
 __device__ __forceinline__ void kload(KeyW& k, uint64_t w, uint32_t y) { k.w = w; k.y = w ? y : KEY_EMPTY; }
 
+// rank += (o is better than key): one-word keys take a compare and an add-with-carry (two vector instructions per
+// candidate in the rank-by-counting loops instead of compare / select / add)
+__device__ __forceinline__ void kcount_better(uint32_t& rank, KeyN o, KeyN key) {
+    asm volatile("v_cmp_gt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(rank) : "v"(o.c), "v"(key.c) : "vcc");
+}
+__device__ __forceinline__ void kcount_better(uint32_t& rank, KeyW o, KeyW key) { rank += kbetter(o, key) ? 1u : 0u; }
+
 // Wave-wide sorted top list: lane i holds the i-th best. Insert the per-lane candidates that beat the k-th.
 template <typename K>
 __device__ __forceinline__ void wave_topk_push(K& best, K cand, int k) {

@@ -46,19 +46,28 @@ def train_epoch(model, users, items, lr, l2=0.0, seed=42, epoch=0, mode=BPR_HOGW
     Data-parallel (one process per GPU, rows sharded by session chunk): pass ``sync`` = an :class:`ItemTableSync` over
     ``model.item_embedding.weight.data``; the item rows the launches touch are exchanged every ``sync_every`` launches
     and the pipeline is drained at the end of the epoch (replicas bit-identical). ``row0`` must be this rank's offset
-    into the global row numbering so that the counter RNG draws different negatives on every rank."""
+    into the global row numbering so that the counter RNG draws different negatives on every rank.
+
+    The exchange schedule is GLOBAL: shards of a session-chunk split hold different numbers of rows, so the number of
+    launch slots of the epoch is the maximum over the ranks (one all-reduce per epoch) and a rank that has run out of
+    rows keeps taking part in the exchanges with empty slots -- every rank issues the same collectives in the same order."""
     n = users.numel()
     n_launch = (n + rows_per_launch - 1) // rows_per_launch
-    eng = model.engine(min(n, rows_per_launch))
-    losses = torch.zeros(n_launch, dtype=torch.float32, device=users.device)
+    n_slots = sync.global_max(n_launch) if sync is not None else n_launch
+    if sync is not None:
+        # small launches report the rows they wrote (sparse exchange possible); decided from arguments every rank shares
+        sync.tracking = rows_per_launch <= sync.mark.numel() // 4
+    eng = model.engine(max(1, min(n, rows_per_launch)))
+    losses = torch.zeros(max(n_launch, 1), dtype=torch.float32, device=users.device)
     U, V = model.user_embedding.weight.data, model.item_embedding.weight.data
-    neg = torch.empty(min(n, rows_per_launch), dtype=torch.int64, device=users.device) if sync is not None else None
-    for q in range(n_launch):
-        lo, hi = q * rows_per_launch, min(n, (q + 1) * rows_per_launch)
-        eng.bpr_step(U, V, users[lo:hi], items[lo:hi], seed, epoch, row0 + lo, lr, l2, mode, loss_sum=losses[q:q + 1],
-                     neg_out=neg)
+    neg = torch.empty(max(1, min(n, rows_per_launch)), dtype=torch.int64, device=users.device) if sync is not None else None
+    for q in range(n_slots):
+        lo, hi = min(n, q * rows_per_launch), min(n, (q + 1) * rows_per_launch)
+        if hi > lo:
+            eng.bpr_step(U, V, users[lo:hi], items[lo:hi], seed, epoch, row0 + lo, lr, l2, mode, loss_sum=losses[q:q + 1],
+                         neg_out=neg)
         if sync is not None:
-            if hi - lo <= sync.mark.numel() // 4:            # few rows: worth tracking them for the sparse exchange
+            if hi > lo and sync.tracking:
                 sync.touched(items[lo:hi], neg[:hi - lo])
             if (q + 1) % sync_every == 0:
                 sync.exchange()
@@ -75,24 +84,36 @@ class ItemTableSync:
     * ``base``   the COMMON table: the initial table plus every delta already exchanged -- bit-identical on all ranks,
     * two persistent exchange buffers (no allocation per call).
 
-    ``exchange()`` (every few launches): this rank's delta since the last exchange, ``V - base``, is summed over the ranks
-    and added to ``base``; ``V`` receives the OTHER ranks' deltas (its own are already in it). Two transports:
+    ``exchange()`` (every few launches): this rank's delta since the last exchange, ``V - base``, is combined over the
+    ranks and added to ``base``; ``V`` receives the OTHER ranks' share (its own is already in it). Two transports:
 
     * dense: one all-reduce of the delta table, started asynchronously on the communication stream and folded in at the
       NEXT exchange, so the collective runs under the following kernel launches (stale-synchronous: foreign updates
       arrive one period late). This is what the full-OTTO shape needs -- 16.7 M triplets per launch touch nearly every
       one of the 1.86 M item rows, so a sparse list would be the whole table plus ids;
-    * sparse: when the rows a rank touched since the last exchange (``touched(ids)``) are few (small batches, tests,
-      fine-tuning), an all-gather of (row id, delta row) pairs -- the exchange section 8 (e) describes -- applied in rank
-      order on every rank.
+    * sparse: in ``tracking`` mode (the caller reports the rows of every launch with ``touched(ids)``; set the same on
+      every rank, e.g. from the launch size) and when the touched rows are few (small batches, tests, fine-tuning): an
+      all-gather of (row id, delta row) pairs -- the exchange section 8 (e) describes -- applied in rank order on every
+      rank. One launch declared ``untracked()`` on any rank makes the period dense: a sparse exchange that knew only
+      some of the written rows would drop the others' updates.
 
-    ``finish()`` drains the pipeline with a blocking exchange and copies ``base`` into ``V``: replicas are bit-identical.
-    Works on any torch.distributed backend (RCCL on the GPUs, gloo in the CPU tests)."""
+    ``reduce``: ``'sum'`` (default) adds the ranks' deltas -- every triplet's SGD step is applied once, exactly as the
+    single-process loop applies it, only later (one launch is already thousands of concurrent steps from one table; W
+    ranks make that W launches). ``'mean'`` divides the combined delta by W (model averaging): a conservative choice
+    when a period is so long that every rank alone drives the hot rows to their optimum and the sum would overshoot; it
+    converges about W times slower per epoch (CPU rehearsal at W = 2 / 4 / 8 in tests/test_distributed_gloo.py: 'sum'
+    ends within a few per cent of the 1-rank loss, 'mean' 9 - 35 % above it).
 
-    def __init__(self, V, group=None, sparse_fraction=0.125):
+    ``finish()`` drains the pipeline with a blocking DENSE exchange and copies ``base`` into ``V``: replicas are
+    bit-identical. Works on any torch.distributed backend (RCCL on the GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, V, group=None, sparse_fraction=0.125, reduce='sum'):
         import torch.distributed as dist
+        if reduce not in ('sum', 'mean'):
+            raise ValueError("reduce must be 'sum' or 'mean'")
         self.dist, self.group = dist, group
         self.world = dist.get_world_size(group)
+        self.scale = 1.0 if reduce == 'sum' else 1.0 / self.world
         self.V = V
         self.base = V.clone()
         self.own = torch.empty_like(V)
@@ -100,22 +121,35 @@ class ItemTableSync:
         self.pending = None
         self.sparse_fraction = sparse_fraction
         self.mark = torch.zeros(V.shape[0], dtype=torch.bool, device=V.device)
-        self.marked = False
+        self.tracking = False            # the caller reports the rows of EVERY launch (same value on every rank)
+        self.all_tracked = True          # tracking: no launch since the last exchange was declared untracked()
         self.stats = {'dense': 0, 'sparse': 0}
 
+    def global_max(self, value):
+        """max of an int over the ranks (one small all-reduce; the epoch's launch-slot count)."""
+        t = torch.tensor([int(value)], dtype=torch.int64, device=self.V.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
     def touched(self, *id_tensors):
-        """Rows the last launches wrote (positives and, from ``neg_out``, negatives); optional -- without it every
-        exchange is dense."""
+        """Rows the last launch wrote (positives and, from ``neg_out``, negatives). Ignored unless ``tracking``."""
+        if not self.tracking:
+            return
         for ids in id_tensors:
             self.mark[ids] = True
-        self.marked = True
+
+    def untracked(self):
+        """A launch whose rows were not reported: the current period is exchanged densely."""
+        self.all_tracked = False
 
     def _fold(self):
-        """Fold a finished asynchronous all-reduce in: base += sum, V += sum - own."""
+        """Fold a finished asynchronous all-reduce in: base += s * sum, V += s * sum - own."""
         if self.pending is None:
             return
         self.pending.wait()
         self.pending = None
+        if self.scale != 1.0:
+            self.red.mul_(self.scale)
         self.base.add_(self.red)
         torch.sub(self.red, self.own, out=self.red)
         self.V.add_(self.red)
@@ -139,19 +173,26 @@ class ItemTableSync:
         me = dist.get_rank(self.group)
         for r in range(W):                                   # rank order on every rank: base stays bit-identical
             i_r, d_r = all_ids[r][:counts[r]], all_rows[r][:counts[r]]
+            if self.scale != 1.0:
+                d_r = d_r * self.scale
             self.base.index_add_(0, i_r, d_r)
             if r != me:
                 self.V.index_add_(0, i_r, d_r)
+            elif self.scale != 1.0:                          # own delta is in V in full: leave the scaled share
+                self.V.index_add_(0, i_r, d_r - all_rows[r][:counts[r]])
         self.stats['sparse'] += 1
 
-    def exchange(self, blocking=False):
+    def exchange(self, blocking=False, allow_sparse=True):
         self._fold()
         use_sparse = False
-        if self.marked:
-            # the same decision on every rank: the largest touched fraction decides
-            frac = torch.tensor([float(self.mark.sum().item()) / self.mark.numel()], dtype=torch.float64, device=self.V.device)
-            self.dist.all_reduce(frac, op=self.dist.ReduceOp.MAX, group=self.group)
-            use_sparse = float(frac.item()) * self.world <= self.sparse_fraction
+        if self.tracking and allow_sparse:
+            # ONE decision for all ranks (`tracking` and `allow_sparse` are the same everywhere, so every rank is here):
+            # sparse only if no rank declared a launch of the period untracked and the largest touched fraction is small;
+            # both travel in one MAX all-reduce. Untracked mode (full-size launches) takes no vote and no host round trip.
+            frac = float(self.mark.sum().item()) / self.mark.numel() if self.all_tracked else 0.0
+            v = torch.tensor([frac, 0.0 if self.all_tracked else 1.0], dtype=torch.float64, device=self.V.device)
+            self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX, group=self.group)
+            use_sparse = float(v[1].item()) == 0.0 and float(v[0].item()) * self.world <= self.sparse_fraction
         if use_sparse:
             self._sparse()
         else:
@@ -161,13 +202,13 @@ class ItemTableSync:
             self.stats['dense'] += 1
             if blocking:
                 self._fold()
-        if self.marked:
+        if self.tracking:
             self.mark.zero_()
-            self.marked = False
+        self.all_tracked = True
 
     def finish(self):
         """Drain: after this call every replica equals the common table bit for bit."""
-        self.exchange(blocking=True)
+        self.exchange(blocking=True, allow_sparse=False)
         self.V.copy_(self.base)
 
 

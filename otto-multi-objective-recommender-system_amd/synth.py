@@ -90,11 +90,16 @@ def generate_sessions(n_sessions, n_aids=OTTO_N_AIDS, seed=42, repeat_p=0.25,
 
 
 def generate_sessions_torch(n_sessions, n_aids=OTTO_N_AIDS, seed=42, device='cuda', repeat_p=0.25,
-                            len_median=6.0, len_sigma=1.435, max_len=500):
+                            len_median=6.0, len_sigma=1.435, max_len=500, pop_seed=None):
     """Same laws as :func:`generate_sessions`, drawn with torch on ``device``.
 
     Returns a dict of device tensors ``aid (int32 bit pattern of uint32), ts int32,
     type uint8, sess_off int64`` plus ``n_aids``.
+
+    ``pop_seed``: the aid popularity table is the one a call with ``seed=pop_seed`` (and the same ``n_sessions``)
+    draws, whatever ``seed`` is -- the ranks of a weak-scaling run (seed = 42 + rank) then sample their sessions
+    from ONE catalogue, as the shards of one OTTO stream would, instead of superposing W different rank laws.
+    ``pop_seed == seed`` (or None) is the single-stream generator unchanged.
     """
     import torch
     g = torch.Generator(device=device)
@@ -110,6 +115,11 @@ def generate_sessions_torch(n_sessions, n_aids=OTTO_N_AIDS, seed=42, device='cud
     pos = torch.arange(E, device=device) - start
 
     pop = torch.exp(math.log(20.0) + 1.88 * torch.randn(n_aids, device=device, dtype=torch.float64, generator=g))
+    if pop_seed is not None and pop_seed != seed:
+        g2 = torch.Generator(device=device)                  # replay the draws a seed=pop_seed call makes before its table
+        g2.manual_seed(pop_seed)
+        torch.randn(n_sessions, device=device, dtype=torch.float32, generator=g2)
+        pop = torch.exp(math.log(20.0) + 1.88 * torch.randn(n_aids, device=device, dtype=torch.float64, generator=g2))
     cdf = torch.cumsum(pop, 0)
     cdf = cdf / cdf[-1]
     u = torch.rand(E, device=device, dtype=torch.float64, generator=g)

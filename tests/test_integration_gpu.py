@@ -217,7 +217,9 @@ def _dp_worker(rank, world, port, q, root, backend='gloo', rows_per_launch=4096,
         model.item_embedding.weight.normal_(0, 0.1)
     model.to(dev)
     # session-chunk shard: users [lo, hi) and their rows belong to this rank
-    lo, hi = n_users * rank // world, n_users * (rank + 1) // world
+    # (unequal chunks: 17,004 and 18,996 rows at two ranks -- the ranks' launch counts differ, the exchange schedule must not)
+    cuts = [0] + [n_users * r // world - 83 for r in range(1, world)] + [n_users]
+    lo, hi = cuts[rank], cuts[rank + 1]
     mine = (u >= lo) & (u < hi)
     du, di = torch.from_numpy(u[mine]).to(dev), torch.from_numpy(i[mine]).to(dev)
     row0 = int(np.flatnonzero(mine)[0])
