@@ -4,9 +4,14 @@
  * Reference code replaced (/root/reference/src/matrix_factorization/torch_trainer.py):
  *   otto_pairs_time   :190-227  'time' strategy: per session-chunk row sample -> session self-join (merge on session) -> drop
  *                               aid_x == aid_y -> target = 0 < ts_y - ts_x <= hour_difference hours -> groupby (aid_x, aid_y)
- *                               mean >= 0.5 or max. The only pair expansion the reference contains. (The `.dt.seconds`
- *                               quirk that drops whole days, SURVEY.md App. E, is not reproduced; sampling is the caller's:
- *                               pass the sampled events.)
+ *                               mean >= 0.5 or max. The only pair expansion the reference contains. Sampling is the
+ *                               caller's: pass the sampled events.
+ *                               DEPARTURE from the reference: the label rule here is 0 < dt <= max_dt_seconds with dt the
+ *                               SIGNED difference in total seconds. The reference reads `(ts_y - ts_x).dt.seconds` (:206), the
+ *                               seconds COMPONENT of the timedelta (0..86399): it drops whole days (25 h later reads as 1 h
+ *                               later: label 1) and turns -10 min into 23 h 50 min (SURVEY.md App. E lists it as a defect).
+ *                               The two rules differ only for |dt| >= 1 day; oracle/pairs_oracle.py and its hand-computed
+ *                               fixture follow the rule stated here.
  *   otto_pairs_diff   :229-255  'diff' strategy: per session x1 = aid, x2 = next aid, x3 = the aid at the same position of a
  *                               random permutation of the session; positives (x1, x2) with x2 != x3, x1 != x2, x1 != x3,
  *                               negatives (x1, x3) with x2 != x3, x1 != x3; de-duplicated, positives win.

@@ -2707,6 +2707,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                     nwalk = nocc;
                     nit = (int)((nwalk + 63u) / 64u);
                 } else if (th <= 64u * SHR) {
+#ifdef OTTO_PHASE_PROF
+                    if (threadIdx.x == 0) ph[14]++;
+#endif
                     if (wid < a.nk && wid < PKD) {
                         const int j = wid;
                         const uint32_t c0 = a.coef[j][0], c1 = a.coef[j][1], c2 = a.coef[j][2];
@@ -3688,7 +3691,7 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
         unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += h[i];
         fprintf(stderr, "[phase-prof] %s items %u  %.3f ms:", tag, n_work, ms);
         for (int i = 0; i < 8; ++i) fprintf(stderr, " p%d %.1f%%", i, tot ? 100.0 * h[i] / tot : 0.0);
-        fprintf(stderr, "  (ticks %llu) guess: tried %llu ok %llu toofew %llu overflow %llu | record wait (not in p2): %.1f%%, next-item fetch (in p1): %.1f%% of the ticks\n", tot, h[8], h[9], h[10], h[11], tot ? 100.0 * (double)h[12] / tot : 0.0, tot ? 100.0 * (double)h[13] / tot : 0.0);
+        fprintf(stderr, "  (ticks %llu) guess: tried %llu ok %llu toofew %llu overflow %llu | record wait (not in p2): %.1f%%, next-item fetch (in p1): %.1f%% of the ticks | single-wave selection of few heavy keys: %llu items\n", tot, h[8], h[9], h[10], h[11], tot ? 100.0 * (double)h[12] / tot : 0.0, tot ? 100.0 * (double)h[13] / tot : 0.0, h[14]);
     };
 #else
     auto prof_begin = [&]() {};

@@ -4,8 +4,9 @@
   (``torch_trainer.py:315-318``: ``Loader(dataset, batch_size, shuffle=True, drop_last=False)``):
   the whole parquet sits in HBM (223.6M rows x 3 x int64 = 5.4 GB of 288 GB) and every epoch
   yields ``(dict_of_int64_device_tensors, None)`` batches in a fresh random order.
-* ``build_sessions_aids`` / ``build_aid_pairs`` restate the dataset builders of
-  ``torch_trainer.py:190-260, 286-287`` (App. E defects not reproduced).
+* ``build_sessions_aids`` / ``build_aid_pairs_device`` are the dataset builders of
+  ``torch_trainer.py:190-260, 286-287`` (App. E defects not reproduced); the aid-pair builders run on the device
+  (``csrc/otto_pairs.hip``), their CPU restatement lives in ``oracle/pairs_oracle.py`` (test infrastructure).
 """
 import numpy as np
 import torch
@@ -76,67 +77,19 @@ def build_sessions_aids(df):
     return out
 
 
-def build_aid_pairs(df, sampling_strategy='diff', chunk_size=30000, hour_difference=1, target_aggregation='mean',
-                    sample_frac=0.15, seed=42, shuffle_keys=None):
-    """Labelled aid pairs (x1, x2, target) of ``torch_trainer.py:190-260``.
-
-    'diff' (``:229-255``): per session x1 = aid, x2 = next aid (positive), x3 = a random aid of the
-    same session (negative); (x1, x2) target 1 and (x1, x3) target 0 with x2 != x3, x1 != x2 / x1 != x3;
-    de-duplicated, positives win over negatives.  'time' (``:190-227``): per session-chunk self-join of a
-    row sample, drop aid_x == aid_y, target = 0 < dt <= hour_difference hours, aggregated per pair by
-    mean >= 0.5 or max.  The reference's sampling/shuffle is unseeded; here it is seeded.
-    """
-    import pandas as pd
-    rng = np.random.default_rng(seed)
-    df = df.assign(ts=_ts_seconds(df['ts'])).sort_values(['session', 'ts'], kind='stable').reset_index(drop=True)
-    if sampling_strategy == 'diff':
-        s = df['session'].to_numpy()
-        a = df['aid'].to_numpy().astype(np.int64)
-        same_next = np.r_[s[1:] == s[:-1], False]
-        x2 = np.r_[a[1:], -1]
-        # random permutation inside each session: sort by a random key per event (ties keep the event order);
-        # ``shuffle_keys`` (one value below 2^31 per event of the sorted frame) pins the draw, e.g. to the device builder's
-        key = rng.integers(0, 2 ** 31, len(a), dtype=np.uint64) if shuffle_keys is None else np.asarray(shuffle_keys, dtype=np.uint64)
-        order = np.lexsort((key, s))
-        x3 = a[order]
-        ok = same_next
-        pos = ok & (x2 != x3) & (a != x2) & (a != x3)
-        neg = ok & (x2 != x3) & (a != x3)
-        P = pd.DataFrame({'x1': a[pos], 'x2': x2[pos], 'target': 1}).drop_duplicates(['x1', 'x2'])
-        N = pd.DataFrame({'x1': a[neg], 'x2': x3[neg], 'target': 0}).drop_duplicates(['x1', 'x2'])
-        out = pd.concat((P, N), ignore_index=True).drop_duplicates(['x1', 'x2'], keep='first')
-    elif sampling_strategy == 'time':
-        sessions = df['session'].unique()
-        parts = []
-        for i in range(0, len(sessions), chunk_size):
-            lo, hi = sessions[i], sessions[min(len(sessions) - 1, i + chunk_size - 1)]
-            c = df[(df['session'] >= lo) & (df['session'] <= hi)]
-            c = c.sample(frac=sample_frac, random_state=int(rng.integers(2 ** 31)))
-            m = c.merge(c, on='session')
-            m = m[m['aid_x'] != m['aid_y']]
-            dt = (m['ts_y'].to_numpy().astype(np.int64) - m['ts_x'].to_numpy().astype(np.int64)) / 3600.0     # hours, signed
-            parts.append(pd.DataFrame({'aid_x': m['aid_x'].to_numpy(), 'aid_y': m['aid_y'].to_numpy(),
-                                       'target': ((dt > 0) & (dt <= hour_difference)).astype(np.int64)}))
-        allp = pd.concat(parts, ignore_index=True)
-        grp = allp.groupby(['aid_x', 'aid_y'])['target']
-        if target_aggregation == 'mean':
-            out = grp.mean().reset_index()
-            out['target'] = (out['target'] >= 0.5).astype(int)
-        elif target_aggregation == 'max':
-            out = grp.max().reset_index()
-        else:
-            raise ValueError('Invalid target aggregation')
-        out = out.rename(columns={'aid_x': 'x1', 'aid_y': 'x2'})
-    else:
-        raise ValueError('Invalid sampling strategy')
-    return out.astype('int64').reset_index(drop=True)
-
-
 def build_aid_pairs_device(ev, sampling_strategy='diff', hour_difference=1, target_aggregation='mean', sample_frac=0.15, seed=42,
                            shuffle_keys=None):
-    """Device form of :func:`build_aid_pairs` (``include/otto_pairs.h``) over a sorted, resident
-    event stream ``ev`` (:class:`otto_amd.events.DeviceEvents`). Returns device int64 tensors ``(x1, x2, target)`` sorted by
-    (x1, x2) -- the same SET of labelled pairs as the host function for the same sample / the same ``shuffle_keys``.
+    """Labelled aid pairs (x1, x2, target) of ``torch_trainer.py:190-260`` (``include/otto_pairs.h``)
+    over a sorted, resident event stream ``ev`` (:class:`otto_amd.events.DeviceEvents`). Returns device int64 tensors
+    ``(x1, x2, target)`` sorted by (x1, x2) -- the same SET of labelled pairs as the CPU restatement
+    ``oracle/pairs_oracle.py`` (test infrastructure) for the same sample / the same ``shuffle_keys``.
+
+    'diff' (``:229-255``): per session x1 = aid, x2 = next aid (positive), x3 = a random aid of the same session
+    (negative); (x1, x2) target 1 and (x1, x3) target 0 with x2 != x3, x1 != x2 / x1 != x3; de-duplicated, positives win
+    over negatives. 'time' (``:190-227``): self-join of a row sample per session, drop aid_x == aid_y, target =
+    0 < dt <= hour_difference hours in signed total seconds (the reference's ``.dt.seconds`` drops whole days:
+    ``include/otto_pairs.h``), aggregated per pair by mean >= 0.5 or max. The reference's sampling / shuffle is
+    unseeded; here it is seeded. There is no host path: the builders need a ROCm device.
 
     'time': the row sample (``sample_frac`` of the events, Bernoulli per event from a seeded device generator; the reference
     samples each 30,000-session chunk unseeded) is drawn here, the self-join, the time predicate and the per-pair mean / max
@@ -147,7 +100,7 @@ def build_aid_pairs_device(ev, sampling_strategy='diff', hour_difference=1, targ
     from .. import _lib
     dev = ev.aid.device
     if dev.type != 'cuda':
-        raise _lib.OttoError('build_aid_pairs_device needs a ROCm device (the host path is build_aid_pairs)')
+        raise _lib.OttoError('build_aid_pairs_device needs a ROCm device (no CPU fallback)')
     if sampling_strategy not in ('time', 'diff'):
         raise ValueError('Invalid sampling strategy')
     if target_aggregation not in ('mean', 'max'):

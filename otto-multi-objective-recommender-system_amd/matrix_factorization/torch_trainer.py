@@ -28,7 +28,7 @@ if __package__ in (None, ''):   # run as a script from its own directory, like t
 
 from .. import settings
 from . import torch_modules, torch_utils, torch_optim, metrics, visualization
-from .data import DeviceBatchLoader, build_aid_pairs, build_aid_pairs_device, build_sessions_aids  # noqa: F401
+from .data import DeviceBatchLoader, build_aid_pairs_device, build_sessions_aids  # noqa: F401
 from .torch_optim import loss_kind
 
 

@@ -66,25 +66,91 @@ def test_metrics_mirror_matches_reference_outputs():
     assert metrics.recall_at_20([[1, 2, 3], [9]], [[3, 4], [9, 9]]) == pytest.approx(2 / 4)
 
 
-def test_aid_pair_builders():
-    from otto_amd.matrix_factorization.data import build_aid_pairs, build_sessions_aids
+def test_aid_pair_oracle_hand_computed_fixture():
+    """oracle/pairs_oracle.py (the checker of the device pair builders) against labels derived
+    by hand from `torch_trainer.py:190-255`.
+
+    'time', hour_difference = 1. Session 1 rows r0 (10, 0 s) r1 (11, 600) r2 (10, 1800) r3 (12, 5400) r4 (11, 90000);
+    every ordered row pair with different aids, label = 0 < ts_y - ts_x <= 3600:
+      (10, 11): r0->r1 +600 -> 1, r0->r4 +90000 (25 h: 0 here; the reference's `.dt.seconds` would read 1 h -> 1),
+                r2->r1 -1200 (negative) -> 0, r2->r4 +88200 -> 0              mean 0.25 -> 0, max 1
+      (10, 12): r0->r3 +5400 -> 0, r2->r3 +3600 (inclusive bound) -> 1        mean 0.5  -> 1 (tie goes up), max 1
+      (11, 10): r1->r0 -600 -> 0, r1->r2 +1200 -> 1, r4->r0, r4->r2 negative  mean 0.25 -> 0, max 1
+      (11, 12), (12, 10), (12, 11): no difference in (0, 3600]                0, 0
+    Session 2: aids 20, 21 with EQUAL timestamps: dt = 0 both ways -> 0.
+
+    'diff'. Session A aids 1, 2, 3, 2 with shuffle keys 5, 1, 5, 0 (a tie on the key keeps the event order): shuffled
+    aids 2, 2, 1, 3. Rows (x1, x2 = next, x3): (1, 2, 2) x2 == x3 -> nothing; (2, 3, 2) x1 == x3 -> nothing;
+    (3, 2, 1) -> positive (3, 2), negative (3, 1); the last row has no next aid. Session B aids 4, 5, 4, 7, 5 with
+    keys 1, 2, 3, 0, 4: shuffled 7, 4, 5, 4, 5. Rows (4, 5, 7) -> positive (4, 5), negative (4, 7); (5, 4, 4) x2 == x3 ->
+    nothing; (4, 7, 5) -> positive (4, 7), negative (4, 5); (7, 5, 4) -> positive (7, 5), negative (7, 4). (4, 5) and
+    (4, 7) are each positive in one row and negative in another: the positive wins."""
+    import pairs_oracle as po
+    df = pd.DataFrame({'session': [1, 1, 1, 1, 1, 2, 2], 'aid': [10, 11, 10, 12, 11, 20, 21],
+                       'ts': [0, 600, 1800, 5400, 90000, 100, 100], 'type': 0})
+    want_mean = {(10, 11): 0, (10, 12): 1, (11, 10): 0, (11, 12): 0, (12, 10): 0, (12, 11): 0, (20, 21): 0, (21, 20): 0}
+    want_max = {**want_mean, (10, 11): 1, (11, 10): 1}
+    base = 1_659_304_800
+    for frame in (df, df.assign(ts=(df['ts'] + base) * 1000), df.assign(ts=pd.to_datetime(df['ts'] + base, unit='s'))):   # s, ms, datetime
+        for agg, want in (('mean', want_mean), ('max', want_max)):
+            for chunk in (1, 30000):
+                got = po.pairs_time(frame, hour_difference=1, target_aggregation=agg, chunk_size=chunk)
+                assert {(a, b): c for a, b, c in got.to_numpy()} == want, (agg, chunk)
+    # a row mask (the reference's 15 % sample): without r2 the pair (10, 12) keeps only its 0 label
+    got = po.pairs_time(df, row_mask=[1, 1, 0, 1, 1, 1, 1])
+    assert {(a, b): c for a, b, c in got.to_numpy()}[(10, 12)] == 0
+    with pytest.raises(ValueError):
+        po.pairs_time(df, target_aggregation='median')
+    dd = pd.DataFrame({'session': [1, 1, 1, 1, 2, 2, 2, 2, 2], 'aid': [1, 2, 3, 2, 4, 5, 4, 7, 5], 'ts': list(range(9)), 'type': 0})
+    got = po.pairs_diff(dd, shuffle_keys=[5, 1, 5, 0, 1, 2, 3, 0, 4])
+    assert not got.duplicated(['x1', 'x2']).any()
+    assert {(a, b): c for a, b, c in got.to_numpy()} == {(3, 2): 1, (3, 1): 0, (4, 5): 1, (4, 7): 1, (7, 5): 1, (7, 4): 0}
+
+
+def test_session_aid_table_builder():
+    from otto_amd.matrix_factorization.data import build_sessions_aids
     df = pd.DataFrame({'session': [1, 1, 1, 2, 2, 3], 'aid': [10, 11, 12, 20, 21, 30],
                        'ts': [0, 1000, 5000, 0, 7200 * 1000, 5], 'type': [0, 1, 2, 0, 0, 1]})
     sa = build_sessions_aids(df)
     assert list(sa.columns) == ['session', 'aid', 'target'] and sa['target'].tolist() == [0, 1, 2, 0, 0, 1] and sa.dtypes.eq('int64').all()
-    p = build_aid_pairs(df, 'diff', seed=1)
-    assert set(p.columns) == {'x1', 'x2', 'target'} and not p.duplicated(['x1', 'x2']).any()
-    pos = p[p['target'] == 1]
-    assert set(map(tuple, pos[['x1', 'x2']].to_numpy())) <= {(10, 11), (11, 12), (20, 21)}
-    # 'time': raw pickle timestamps are uint64 MILLISECONDS since the epoch (dataset_writer_pickle.py:59); the self-join
-    # holds every pair in both directions, so ts_y < ts_x occurs and must not wrap
-    df['ts'] = (np.uint64(1_659_304_800_000) + df['ts'].to_numpy().astype(np.uint64))
-    assert df['ts'].dtype == np.uint64
-    for frame in (df, df.assign(ts=df['ts'] // 1000), df.assign(ts=pd.to_datetime(df['ts'], unit='ms'))):   # ms, s, datetime
-        t = build_aid_pairs(frame, 'time', chunk_size=2, hour_difference=1, target_aggregation='max', sample_frac=1.0)
-        d = {(a, b): c for a, b, c in t.to_numpy()}
-        assert d[(10, 11)] == 1 and d[(10, 12)] == 1 and d[(11, 10)] == 0 and d[(12, 10)] == 0
-        assert d[(20, 21)] == 0 and d[(21, 20)] == 0                       # 2 h apart: outside the 1 h window either way
+
+
+def test_interaction_feature_oracle_hand_computed_fixture():
+    """oracle/inter_oracle.py (the checker of `otto_inter_features`) against values derived by hand
+    from `interaction_feature_engineering.py:56-113`. Session 7 = aids 5 (click), 6 (cart), 5 (order): positions 1, 2, 3;
+    session 8 = aid 9. Candidates: session 7 -> 5 (score 3), 6 (2), 100 (1; never seen); session 8 -> 100 (4): a
+    one-candidate session (std null) whose candidate is absent (cumcount null, sums of all-null = 0)."""
+    import inter_oracle as io
+    ev = pd.DataFrame({'session': [7, 7, 7, 8], 'aid': [5, 6, 5, 9], 'ts': [1, 2, 3, 1], 'type': [0, 1, 2, 0]})
+    cand = pd.DataFrame({'session': [7, 7, 7, 8], 'candidates': [5, 6, 100, 100], 'candidate_scores': [3.0, 2.0, 1.0, 4.0]})
+    out = io.interaction_features(cand, ev).set_index(['session', 'candidates'])
+    nan = float('nan')
+
+    def row(key, **want):
+        for name, v in want.items():
+            got = out.loc[key, name]
+            assert (np.isnan(got) and np.isnan(v)) or got == pytest.approx(v), (key, name, got, v)
+    row((7, 5), session_candidate_occurrence_count=2, session_candidate_cumcount_last=3, session_candidate_click_occurrence_count=1,
+        session_candidate_cart_occurrence_count=0, session_candidate_order_occurrence_count=1)
+    row((7, 6), session_candidate_occurrence_count=1, session_candidate_cumcount_last=2, session_candidate_cart_occurrence_count=1)
+    row((7, 100), session_candidate_occurrence_count=0, session_candidate_cumcount_last=nan, session_candidate_click_occurrence_count=0)
+    for key in ((7, 5), (7, 6), (7, 100)):
+        row(key, session_candidate_score_mean=2.0, session_candidate_score_std=1.0, session_candidate_score_min=1.0,
+            session_candidate_score_max=3.0, session_candidate_occurrence_count_mean=1.0, session_candidate_occurrence_count_sum=3,
+            session_candidate_occurrence_count_max=2, session_candidate_cumcount_last_mean=2.5,
+            session_candidate_cumcount_last_sum=5, session_candidate_cumcount_last_max=3)
+    row((8, 100), session_candidate_score_mean=4.0, session_candidate_score_std=nan, session_candidate_score_min=4.0,
+        session_candidate_score_max=4.0, session_candidate_occurrence_count_mean=0.0, session_candidate_occurrence_count_sum=0,
+        session_candidate_occurrence_count_max=0, session_candidate_cumcount_last_mean=nan, session_candidate_cumcount_last_sum=0,
+        session_candidate_cumcount_last_max=nan)
+    row((7, 5), aid_candidate_score_mean=3.0, aid_candidate_score_std=nan, aid_candidate_score_max=3.0,
+        aid_session_candidate_occurrence_count_mean=2.0, aid_session_candidate_occurrence_count_sum=2,
+        aid_session_candidate_cumcount_last_mean=3.0, aid_session_candidate_cumcount_last_sum=3, aid_session_candidate_cumcount_last_max=3)
+    for key in ((7, 100), (8, 100)):
+        row(key, aid_candidate_score_mean=2.5, aid_candidate_score_std=4.5 ** 0.5, aid_candidate_score_max=4.0,
+            aid_session_candidate_occurrence_count_mean=0.0, aid_session_candidate_occurrence_count_sum=0,
+            aid_session_candidate_occurrence_count_max=0, aid_session_candidate_cumcount_last_mean=nan,
+            aid_session_candidate_cumcount_last_sum=0, aid_session_candidate_cumcount_last_max=nan)
 
 
 def test_mf_score_functions_match_sklearn_and_loader_range_check():
@@ -185,6 +251,7 @@ def _table_sync_worker(rank, world, port, q):
     n, d = 4000, 8
     V = torch.randn(n, d, generator=g)
     sync = ItemTableSync(V, sparse_fraction=0.125)
+    sync.tracking = True                       # the caller reports every launch: touched() or untracked()
     total = torch.zeros_like(V)
     gr = torch.Generator().manual_seed(100 + rank)
     every = [torch.Generator().manual_seed(100 + r) for r in range(world)]
@@ -198,6 +265,8 @@ def _table_sync_worker(rank, world, port, q):
         V.index_add_(0, ids, upd)
         if mark:
             sync.touched(ids)
+        else:
+            sync.untracked()
         for gen in every:                                               # what the sum of all ranks' updates must be
             i2, u2 = period(gen, rows)
             total.index_add_(0, i2, u2)
