@@ -121,3 +121,61 @@ def test_c_restatement_matches_numpy_and_hand_values():
     assert d == {p: w * Q for p, w in HAND['cart_weighted'].items()}
     d = dict(zip(zip(got['time_weighted'][0].tolist(), got['time_weighted'][1].tolist()), got['time_weighted'][2].tolist()))
     assert d == HAND_TIME
+
+
+def test_c_restatement_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """SURVEY.md section 5 (CPU-side sanitizers; never on the GPU box): `make -C oracle asan` builds covis_oracle.c with
+    -fsanitize=address,undefined behind a file-driven main; it runs the hand-derived micro-sessions, random sessions with
+    window 32 (the table bound of the expansion), an empty stream and length-1 sessions, with 1 and 4 threads. A sanitizer
+    report or a difference between the two runs fails the process; its rows must equal the NumPy restatement's."""
+    import subprocess
+    oracle_dir = os.path.join(os.path.dirname(os.path.abspath(co.__file__)))
+    r = subprocess.run(['make', '-C', oracle_dir, 'asan'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    exe = os.path.join(oracle_dir, '_build', 'covis_oracle_asan')
+    from covis_oracle_c import covis_topk_c  # noqa: F401  (same kind encoding as the ctypes wrapper)
+    kinds = co.ALL_KINDS
+    group, param = [], []
+    for kd in kinds:
+        if kd == 'time_weighted':
+            group.append(0); param += [0, 0, 0]
+        elif kd in co.TYPE_WEIGHTS:
+            group.append(1); param += list(co.TYPE_WEIGHTS[kd])
+        else:
+            m = co.FILTER_MASKS[kd]
+            group.append(2); param += [sum(1 << (tx * 3 + ty) for tx in range(3) for ty in range(3) if m[tx][ty]), 0, 0]
+    ev = generate_sessions(300, n_aids=40, seed=9, max_len=70)
+    lone = (np.array([3, 4, 5], dtype=np.uint32), np.array([T, T + 1, T + 2], dtype=np.int32), np.zeros(3, dtype=np.uint8),
+            np.array([0, 1, 2, 3], dtype=np.int64))                       # three sessions of one event: no pair
+    empty = (np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64))
+    cases = [(_micro(), 31, 30, 86400, 20), ((ev.aid, ev.ts, ev.type, ev.sess_off), 40, 32, 86400, 20),
+             ((ev.aid, ev.ts, ev.type, ev.sess_off), 40, 5, 600, 3), (lone, 8, 30, 86400, 20), (empty, 8, 30, 86400, 20)]
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='print_stacktrace=1')
+    for ci, ((aid, ts, typ, off), n_aids, window, gap, k) in enumerate(cases):
+        t0, t1 = (int(ts.min()), int(ts.max())) if len(ts) else (0, 0)
+        src, dst = tmp_path / f'case{ci}.bin', tmp_path / f'out{ci}.bin'
+        with open(src, 'wb') as f:
+            f.write(np.array([len(off) - 1, len(aid), n_aids, window, gap, t0, t1, len(kinds), k], dtype=np.int64).tobytes())
+            f.write(np.array(group, dtype=np.int32).tobytes())
+            f.write(np.array(param, dtype=np.int32).tobytes())
+            for a in (off.astype(np.int64), aid.astype(np.uint32), ts.astype(np.int32), typ.astype(np.uint8)):
+                f.write(a.tobytes())
+        r = subprocess.run([exe, str(src), str(dst)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=300)
+        assert r.returncode == 0 and 'runtime error' not in r.stdout and 'AddressSanitizer' not in r.stdout, f'case {ci}:\n{r.stdout}'
+        raw = open(dst, 'rb').read()
+        nk = len(kinds)
+        P = int(np.frombuffer(raw, dtype=np.int64, count=1)[0])
+        o = 8
+        oy = np.frombuffer(raw, dtype=np.uint32, count=nk * n_aids * k, offset=o).reshape(nk, n_aids, k); o += oy.nbytes
+        ow = np.frombuffer(raw, dtype=np.uint64, count=nk * n_aids * k, offset=o).reshape(nk, n_aids, k); o += ow.nbytes
+        on = np.frombuffer(raw, dtype=np.int32, count=nk * n_aids, offset=o).reshape(nk, n_aids)
+        st = {}
+        want = co.covis_topk_numpy(aid, ts, typ, off, co.CovisSpec(window=window, max_gap=gap), k=k, stats=st) if len(aid) else None
+        assert P == (st['P'] if want is not None else 0)
+        for j, kd in enumerate(kinds):
+            valid = np.arange(k)[None, :] < on[j][:, None]
+            x = np.broadcast_to(np.arange(n_aids, dtype=np.uint32)[:, None], (n_aids, k))[valid]
+            if want is None:
+                assert x.size == 0
+                continue
+            assert np.array_equal(x, want[kd][0]) and np.array_equal(oy[j][valid], want[kd][1]) and np.array_equal(ow[j][valid], want[kd][2]), (ci, kd)
