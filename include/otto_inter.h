@@ -39,6 +39,14 @@ int otto_inter_features(const uint32_t* d_aid, const uint8_t* d_type, const int6
                         const int32_t* d_cand, const float* d_score, int32_t C, uint32_t n_aids, uint16_t* d_row,
                         float* d_sess_feat, float* d_aid_feat, void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* The same features over the CSR rows of the ranker's candidate table (otto_cand_ranker_table, include/otto_cand.h): session s
+ * owns rows [d_cand_off[s], d_cand_off[s + 1]) of d_cand / d_score -- the session's own aids followed by the candidates, the
+ * frame src/ranker/interaction_feature_engineering.py:25-28 reads. d_row u16 [n_rows][5]. */
+int otto_inter_features_rows(const uint32_t* d_aid, const uint8_t* d_type, const int64_t* d_sess_off, int64_t n_sess,
+                             const int64_t* d_cand_off, const int32_t* d_cand, const float* d_score, uint32_t n_aids,
+                             uint16_t* d_row, float* d_sess_feat, float* d_aid_feat, void* d_workspace, int64_t workspace_bytes,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,3 +68,15 @@ def session_predictions(session_aids, sorted_aids, most_frequent, n_pred=20):
     predictions = session_unique_aids + sorted_aids[:n_pred - len(session_unique_aids)]
     predictions = predictions + most_frequent[:n_pred - len(predictions)]
     return predictions
+
+
+def session_ranker_rows(session_aids, sorted_aids, sorted_counts, labels=None):
+    """``src/ranker/regular_candidate_generation.py:160-193`` for one session and one event type: ``sorted_aids`` /
+    ``sorted_counts`` = ``[(aid, weight) for aid, weight in Counter(...).most_common(100) if aid not in session_unique_aids]``
+    (:160); returns (predictions, scores, labels)."""
+    session_unique_aids = list(dict.fromkeys(list(map(int, session_aids))[::-1]))
+    scores = np.arange(1, len(session_unique_aids) + 1).tolist()[::-1] + list(sorted_counts)          # :162
+    predictions = session_unique_aids + list(sorted_aids)                                               # :178
+    lab = None if labels is None else [int(aid in labels) for aid in predictions]                       # :191-193
+    return predictions, scores, lab
+

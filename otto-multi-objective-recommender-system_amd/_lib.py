@@ -112,6 +112,9 @@ SIGNATURES = {
     'otto_cand_lookup_self': (_i32, [C.POINTER(CandParams), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     'otto_recency_predictions': (_i32, [C.POINTER(RecencyPredParams), _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     'otto_cand_predictions': (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    'otto_cand_ranker_workspace': (_i64, [_i64]),
+    'otto_cand_ranker_rows': (_i32, [_vp, _vp, _i64, _vp, _i32, _vp, _p_i64, _vp, _i64, _vp]),
+    'otto_cand_ranker_table': (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'otto_recency_candidates': (_i32, [C.POINTER(RecencyParams), _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     # include/otto_events.h
     'otto_events_sort_workspace': (_i64, [_i64]),
@@ -125,6 +128,7 @@ SIGNATURES = {
     # include/otto_inter.h
     'otto_inter_workspace': (_i64, [_u32]),
     'otto_inter_features': (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _u32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'otto_inter_features_rows': (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _i64, _vp]),
     # include/otto_mf.h
     'otto_mf_create': (_i32, [C.POINTER(_vp), _i64, _i64, _i32, _i64, _i32]),
     'otto_mf_destroy': (None, [_vp]),

@@ -91,6 +91,51 @@ def predictions(aid, sess_off, cand, n_cand, most_frequent, n_pred=20):
     return pred, n_out
 
 
+def ranker_table(aid, sess_off, cand, count, n_cand, labels=None, session_ids=None):
+    """The ranker's candidate table (``src/ranker/regular_candidate_generation.py:160-193,236-244``) from the outputs of
+    :func:`candidate_lookup` (``INFERENCE_*_RECIPE``, ``n_common=100``), on the device: per session the unique aids, most
+    recent first, scored ``u, u-1, .., 1``, then the candidates scored with their Counter counts; ``labels`` = CSR pair
+    ``(label_off int64 [S+1], label_aid int32)`` of the type's ground truth (None: no label column, test mode);
+    ``session_ids`` int64 [S] = the values of the ``session`` column (None: the session's index).
+    Returns a dict of device tensors ``session`` int64, ``candidates`` int32, ``candidate_scores`` float32,
+    ``candidate_labels`` uint8 (or None) -- one row per (session, candidate) -- and ``row_off`` int64 [S+1]; this is the
+    frame ``ranker.interaction_feature_engineering.interaction_features_rows`` takes."""
+    import torch
+    dev = aid.device
+    if dev.type != 'cuda':
+        raise _lib.OttoError('ranker_table needs a ROCm device (no CPU fallback)')
+    for name, x, dt in (('aid', aid, torch.int32), ('sess_off', sess_off, torch.int64), ('cand', cand, torch.int32),
+                        ('count', count, torch.int32), ('n_cand', n_cand, torch.int32)):
+        if x.dtype != dt or not x.is_contiguous():
+            raise ValueError(f'{name}: expected contiguous {dt}')
+    S, n_common = sess_off.numel() - 1, int(cand.shape[1])
+    if cand.shape != count.shape or cand.shape[0] != S or n_cand.numel() != S:
+        raise ValueError('cand / count / n_cand shapes disagree with sess_off')
+    lib = _lib.lib()
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else C.c_void_p(0)
+    stream = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev):
+        ws_b = int(lib.otto_cand_ranker_workspace(S))
+        ws = torch.empty(max(ws_b, 8), dtype=torch.uint8, device=dev)
+        row_off = torch.empty(S + 1, dtype=torch.int64, device=dev)
+        n_rows = C.c_int64()
+        _lib.check(lib.otto_cand_ranker_rows(p(aid), p(sess_off), S, p(n_cand), n_common, p(row_off), C.byref(n_rows), p(ws), ws_b, stream()),
+                   'otto_cand_ranker_rows')
+        R = int(n_rows.value)
+        out = {'session': torch.empty(R, dtype=torch.int64, device=dev), 'candidates': torch.empty(R, dtype=torch.int32, device=dev),
+               'candidate_scores': torch.empty(R, dtype=torch.float32, device=dev),
+               'candidate_labels': torch.empty(R, dtype=torch.uint8, device=dev) if labels is not None else None, 'row_off': row_off}
+        l_off, l_aid = (None, None) if labels is None else labels
+        if labels is not None and (l_off.dtype != torch.int64 or l_aid.dtype != torch.int32 or l_off.numel() != S + 1):
+            raise ValueError('labels: expected (int64 [S+1], int32) CSR lists')
+        if session_ids is not None and (session_ids.dtype != torch.int64 or session_ids.numel() != S):
+            raise ValueError('session_ids: expected int64 [S]')
+        _lib.check(lib.otto_cand_ranker_table(p(aid), p(sess_off), S, p(cand), p(count), p(n_cand), n_common, p(row_off), p(l_off), p(l_aid),
+                                              p(session_ids), p(out['session']), p(out['candidates']), p(out['candidate_scores']),
+                                              p(out['candidate_labels']), stream()), 'otto_cand_ranker_table')
+    return out
+
+
 # curves and type coefficients of src/ranker/recency_weighted_candidate_generator.py:24,68-70
 RECENCY_CURVES = ((0.1, 1.0), (0.5, 1.0))            # clicks; carts and orders
 RECENCY_TYPE_COEFFICIENT = (1.0, 6.0, 1.0)

@@ -12,6 +12,7 @@
 //      selections (topk.h), then drop the session's own aids and compact
 #include "common.h"
 #include "topk.h"
+#include "scan.h"
 #include "../../include/otto_cand.h"
 
 #include <string.h>
@@ -421,6 +422,72 @@ __global__ __launch_bounds__(64) void k_predictions(const uint32_t* aid, const i
     }
 }
 
+// ---- the ranker's candidate table (src/ranker/regular_candidate_generation.py:160-193) ---------------------------------
+// One wave per session. A row block = the session's unique aids, most recent first, scored u, u-1, .., 1, followed by the
+// lookup's candidates scored with their Counter counts; label = the aid is in the session's label list of the type.
+// COUNT: only the number of rows (rows[s] = u + candidates kept). The unique walk is the one of k_predictions: backwards,
+// 64 events at a time, an event enters if no LATER event holds its aid.
+template <bool COUNT>
+__global__ __launch_bounds__(64) void k_ranker_table(const uint32_t* aid, const int64_t* off, int64_t n_sess, const int32_t* cand,
+                                                      const int32_t* count, const int32_t* n_cand, int n_common, uint32_t* rows,
+                                                      const uint64_t* row_off, const int64_t* label_off, const int32_t* label_aid,
+                                                      const int64_t* session_ids, int64_t* o_session, int32_t* o_cand, float* o_score,
+                                                      uint8_t* o_label) {
+    const unsigned lane = lane_id();
+    for (int64_t s = blockIdx.x; s < n_sess; s += gridDim.x) {
+        const int64_t lo = off[s], hi = off[s + 1];
+        const int nc = n_cand[s] < n_common ? (n_cand[s] > 0 ? n_cand[s] : 0) : n_common;
+        const int64_t l0 = (!COUNT && label_off) ? label_off[s] : 0, l1 = (!COUNT && label_off) ? label_off[s + 1] : 0;
+        auto is_label = [&](uint32_t x) {
+            bool hit = false;
+            for (int64_t q = l0; q < l1; ++q) hit = hit || (uint32_t)label_aid[q] == x;
+            return hit;
+        };
+        int u = 0;
+        if (!COUNT) {                    // scores of the unique aids need u first: the fill pass reads it from the row offsets
+            u = (int)(row_off[s + 1] - row_off[s]) - nc;
+        }
+        int filled = 0;
+        const int64_t base = COUNT ? 0 : (int64_t)row_off[s];
+        const int64_t sid = (!COUNT && session_ids) ? session_ids[s] : s;
+        for (int64_t top = hi; top > lo; top -= 64) {
+            const int64_t i = top - 1 - (int64_t)lane;
+            bool first = false;
+            uint32_t x = 0;
+            if (i >= lo) {
+                x = aid[i];
+                first = true;
+                for (int64_t j = i + 1; j < hi; ++j)
+                    if (aid[j] == x) { first = false; break; }
+            }
+            const uint64_t m = __ballot(first);
+            if (!COUNT && first) {
+                const int pos = filled + (int)__popcll(m & ((1ull << lane) - 1ull));
+                o_session[base + pos] = sid;
+                o_cand[base + pos] = (int32_t)x;
+                o_score[base + pos] = (float)(u - pos);                 // np.arange(1, u + 1)[::-1]
+                if (o_label) o_label[base + pos] = is_label(x) ? 1 : 0;
+            }
+            filled += (int)__popcll(m);
+        }
+        if (COUNT) {
+            if (lane == 0) rows[s] = (uint32_t)(filled + nc);
+            continue;
+        }
+        for (int c = (int)lane; c < nc; c += 64) {
+            const int32_t y = cand[s * n_common + c];
+            o_session[base + u + c] = sid;
+            o_cand[base + u + c] = y;
+            o_score[base + u + c] = (float)count[s * n_common + c];
+            if (o_label) o_label[base + u + c] = is_label((uint32_t)y) ? 1 : 0;
+        }
+    }
+}
+struct RowsU32 {
+    const uint32_t* r;
+    __device__ uint64_t operator()(int64_t i) const { return r[i]; }
+};
+
 // ---- recency-weighted candidates (section 8 f3) ------------------------------------------------------------------
 struct RecencyArgs {
     otto_recency_params p;
@@ -754,6 +821,51 @@ extern "C" int otto_cand_predictions(const uint32_t* d_aid, const int64_t* d_ses
     OTTO_REQUIRE(d_aid && d_sess_off && d_cand && d_n_cand && d_pred && d_n_pred && (d_frequent || n_frequent == 0), "otto_cand_predictions: null argument");
     k_predictions<<<(unsigned)(n_sess < 256 * 64 ? n_sess : 256 * 64), 64, 0, (hipStream_t)stream>>>(
         d_aid, d_sess_off, n_sess, d_cand, d_n_cand, n_common, d_frequent, n_frequent, n_pred, d_pred, d_n_pred);
+    OTTO_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int64_t otto_cand_ranker_workspace(int64_t n_sess) {
+    return (int64_t)(n_sess > 0 ? n_sess : 1) * 4 + (int64_t)scan_partial_bytes(n_sess > 0 ? n_sess : 1) + 64;
+}
+
+extern "C" int otto_cand_ranker_rows(const uint32_t* d_aid, const int64_t* d_sess_off, int64_t n_sess, const int32_t* d_n_cand,
+                                     int32_t n_common, int64_t* d_row_off, int64_t* h_n_rows, void* d_ws, int64_t ws_bytes,
+                                     void* stream) {
+    OTTO_REQUIRE(n_sess >= 0 && n_common >= 0 && d_row_off && h_n_rows, "otto_cand_ranker_rows: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    *h_n_rows = 0;
+    if (n_sess == 0) {
+        OTTO_HIP(hipMemsetAsync(d_row_off, 0, 8, s));
+        return 0;
+    }
+    OTTO_REQUIRE(d_aid && d_sess_off && d_n_cand && d_ws, "otto_cand_ranker_rows: null argument");
+    OTTO_REQUIRE(ws_bytes >= otto_cand_ranker_workspace(n_sess), "workspace too small");
+    uint32_t* rows = (uint32_t*)d_ws;
+    uint64_t* partial = (uint64_t*)((char*)d_ws + (((size_t)n_sess * 4 + 63) & ~(size_t)63));
+    k_ranker_table<true><<<(unsigned)(n_sess < 256 * 64 ? n_sess : 256 * 64), 64, 0, s>>>(
+        d_aid, d_sess_off, n_sess, nullptr, nullptr, d_n_cand, n_common, rows, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+        nullptr, nullptr);
+    OTTO_HIP(hipGetLastError());
+    OTTO_TRY(device_scan(RowsU32{rows}, n_sess, (uint64_t*)d_row_off, partial, s));
+    OTTO_HIP(hipMemcpyAsync(h_n_rows, d_row_off + n_sess, 8, hipMemcpyDeviceToHost, s));
+    OTTO_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int otto_cand_ranker_table(const uint32_t* d_aid, const int64_t* d_sess_off, int64_t n_sess, const int32_t* d_cand,
+                                      const int32_t* d_count, const int32_t* d_n_cand, int32_t n_common, const int64_t* d_row_off,
+                                      const int64_t* d_label_off, const int32_t* d_label_aid, const int64_t* d_session_ids,
+                                      int64_t* d_out_session, int32_t* d_out_cand, float* d_out_score, uint8_t* d_out_label,
+                                      void* stream) {
+    OTTO_REQUIRE(n_sess >= 0 && n_common >= 0, "otto_cand_ranker_table: bad argument");
+    if (n_sess == 0) return 0;
+    OTTO_REQUIRE(d_aid && d_sess_off && d_n_cand && d_row_off && d_out_session && d_out_cand && d_out_score && (n_common == 0 || (d_cand && d_count)),
+                 "otto_cand_ranker_table: null argument");
+    OTTO_REQUIRE(!d_out_label || !d_label_off || d_label_aid, "otto_cand_ranker_table: label lists without aids");
+    k_ranker_table<false><<<(unsigned)(n_sess < 256 * 64 ? n_sess : 256 * 64), 64, 0, (hipStream_t)stream>>>(
+        d_aid, d_sess_off, n_sess, d_cand, d_count, d_n_cand, n_common, nullptr, (const uint64_t*)d_row_off, d_label_off, d_label_aid,
+        d_session_ids, d_out_session, d_out_cand, d_out_score, d_out_label);
     OTTO_HIP(hipGetLastError());
     return 0;
 }

@@ -38,9 +38,11 @@ __device__ __forceinline__ uint32_t wave_min_u(uint32_t v) {
     return v;
 }
 
+// cand_off == nullptr: dense rows, session s owns cand[s * C, +C) (-1 padded); else the CSR rows of the ranker's candidate
+// table, session s owns cand[cand_off[s], cand_off[s + 1]) (any length: the session's own aids + up to 100 candidates)
 __global__ __launch_bounds__(256) void k_inter_rows(const uint32_t* aid, const uint8_t* type, const int64_t* off, int64_t n_sess,
-                                                    const int32_t* cand, const float* score, int C, uint32_t n_aids, uint16_t* row,
-                                                    float* sess_feat, AidAcc* acc, uint32_t* err) {
+                                                    const int32_t* cand, const float* score, int C, const int64_t* cand_off,
+                                                    uint32_t n_aids, uint16_t* row, float* sess_feat, AidAcc* acc, uint32_t* err) {
     __shared__ uint32_t s_aid[4][OTTO_INTER_MAX_SESSION];
     __shared__ uint8_t s_type[4][OTTO_INTER_MAX_SESSION];
     const int w = threadIdx.x >> 6;
@@ -59,9 +61,11 @@ __global__ __launch_bounds__(256) void k_inter_rows(const uint32_t* aid, const u
         __builtin_amdgcn_wave_barrier();
         double sc_sum = 0, sc_sq = 0, occ_sum = 0, last_sum = 0;
         uint32_t rows = 0, last_rows = 0, occ_max = 0, last_max = 0, sc_max = 0, sc_min = 0xFFFFFFFFu;
-        for (int c0 = 0; c0 < C; c0 += 64) {
+        const int64_t cb = cand_off ? cand_off[s] : s * (int64_t)C;
+        const int Cs = cand_off ? (int)(cand_off[s + 1] - cb) : C;
+        for (int c0 = 0; c0 < Cs; c0 += 64) {
             const int c = c0 + (int)lane;
-            const int32_t y = c < C ? cand[s * C + c] : -1;
+            const int32_t y = c < Cs ? cand[cb + c] : -1;
             uint32_t cnt[3] = {0, 0, 0}, last = 0;
             if (y >= 0) {
                 for (int i = 0; i < n; ++i) {
@@ -72,9 +76,9 @@ __global__ __launch_bounds__(256) void k_inter_rows(const uint32_t* aid, const u
                     }
                 }
                 const uint32_t occ = cnt[0] + cnt[1] + cnt[2];
-                uint16_t* r = row + ((size_t)s * C + c) * OTTO_INTER_ROW_FEATURES;
+                uint16_t* r = row + ((size_t)cb + c) * OTTO_INTER_ROW_FEATURES;
                 r[0] = (uint16_t)occ; r[1] = (uint16_t)last; r[2] = (uint16_t)cnt[0]; r[3] = (uint16_t)cnt[1]; r[4] = (uint16_t)cnt[2];
-                const float f = score[s * C + c];
+                const float f = score[cb + c];
                 const uint32_t fo = float_order(f);
                 sc_sum += (double)f; sc_sq += (double)f * (double)f;
                 sc_max = fo > sc_max ? fo : sc_max; sc_min = fo < sc_min ? fo : sc_min;
@@ -92,8 +96,8 @@ __global__ __launch_bounds__(256) void k_inter_rows(const uint32_t* aid, const u
                 } else {
                     atomicAdd(err, 1u);
                 }
-            } else if (c < C) {
-                uint16_t* r = row + ((size_t)s * C + c) * OTTO_INTER_ROW_FEATURES;
+            } else if (c < Cs) {
+                uint16_t* r = row + ((size_t)cb + c) * OTTO_INTER_ROW_FEATURES;
                 r[0] = r[1] = r[2] = r[3] = r[4] = 0;
             }
         }
@@ -165,7 +169,33 @@ extern "C" int otto_inter_features(const uint32_t* d_aid, const uint8_t* d_type,
         OTTO_REQUIRE(d_aid && d_type && d_sess_off && d_cand && d_score && d_row && d_sess_feat, "otto_inter_features: null argument");
         const int64_t blocks = (n_sess + 3) / 4;
         k_inter_rows<<<(unsigned)(blocks < 256 * 16 ? blocks : 256 * 16), 256, 0, s>>>(d_aid, d_type, d_sess_off, n_sess, d_cand, d_score, C,
-                                                                                      n_aids, d_row, d_sess_feat, acc, err);
+                                                                                      nullptr, n_aids, d_row, d_sess_feat, acc, err);
+        OTTO_HIP(hipGetLastError());
+    }
+    k_inter_aids<<<(n_aids + 255) / 256, 256, 0, s>>>(acc, n_aids, d_aid_feat);
+    OTTO_HIP(hipGetLastError());
+    uint32_t herr = 0;
+    OTTO_HIP(hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, s));
+    OTTO_HIP(hipStreamSynchronize(s));
+    OTTO_REQUIRE(herr == 0, "%u sessions longer than %d events or candidates outside [0, n_aids)", herr, OTTO_INTER_MAX_SESSION);
+    return 0;
+}
+
+extern "C" int otto_inter_features_rows(const uint32_t* d_aid, const uint8_t* d_type, const int64_t* d_sess_off, int64_t n_sess,
+                                        const int64_t* d_cand_off, const int32_t* d_cand, const float* d_score, uint32_t n_aids,
+                                        uint16_t* d_row, float* d_sess_feat, float* d_aid_feat, void* d_ws, int64_t ws_bytes,
+                                        void* stream) {
+    OTTO_REQUIRE(n_sess >= 0 && n_aids > 0 && d_aid_feat && d_ws, "otto_inter_features_rows: bad argument");
+    OTTO_REQUIRE(ws_bytes >= otto_inter_workspace(n_aids), "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    AidAcc* acc = (AidAcc*)((char*)d_ws + 256);
+    uint32_t* err = (uint32_t*)d_ws;
+    OTTO_HIP(hipMemsetAsync(d_ws, 0, (size_t)otto_inter_workspace(n_aids), s));
+    if (n_sess > 0) {
+        OTTO_REQUIRE(d_aid && d_type && d_sess_off && d_cand_off && d_cand && d_score && d_row && d_sess_feat, "otto_inter_features_rows: null argument");
+        const int64_t blocks = (n_sess + 3) / 4;
+        k_inter_rows<<<(unsigned)(blocks < 256 * 16 ? blocks : 256 * 16), 256, 0, s>>>(d_aid, d_type, d_sess_off, n_sess, d_cand, d_score, 0,
+                                                                                      d_cand_off, n_aids, d_row, d_sess_feat, acc, err);
         OTTO_HIP(hipGetLastError());
     }
     k_inter_aids<<<(n_aids + 255) / 256, 256, 0, s>>>(acc, n_aids, d_aid_feat);

@@ -167,6 +167,81 @@ def test_inference_recipes_with_neighbour_term_and_final_predictions(gpu_device)
             assert npred[s] == len(wp) and pred[s, :npred[s]].tolist() == wp and (pred[s, npred[s]:] == -1).all(), s
 
 
+def test_ranker_candidate_table_and_its_interaction_features(gpu_device):
+    """The unbroken device chain of `src/ranker/regular_candidate_generation.py:138-197` -> `:236-244` ->
+    `src/ranker/interaction_feature_engineering.py:25-113`: covisitation lists + the 20 neighbours of the last aid,
+    `most_common(100)` minus the session's aids (otto_cand_lookup), then the ranker's table -- the session's unique aids
+    (most recent first, scores u .. 1) followed by the candidates (scores = counts), labels from the type's ground-truth
+    lists (otto_cand_ranker_table) -- and the interaction features over THAT table (otto_inter_features_rows), which holds
+    the session's own aids, i.e. rows with occurrence counts > 0. Table identical to the oracle's stdlib expressions;
+    features: integers exact, float32 aggregates 1e-5 against the pandas restatement (parity unpinned: polars absent)."""
+    import pandas as pd
+    import torch
+    import inter_oracle as io
+    from otto_amd.covisitation import candidates as cd
+    from otto_amd.ranker import interaction_feature_engineering as ife
+    ev = generate_sessions(900, n_aids=500, seed=41)
+    mats = dict(_matrices(ev, gpu_device, k=15))
+    rng = np.random.default_rng(9)
+    nb = np.stack([rng.permutation(ev.n_aids)[:20] for _ in range(ev.n_aids)]).astype(np.int32)      # stand-in for fastText + Annoy (:150-152)
+    nb_n = np.full(ev.n_aids, 20, dtype=np.int32)
+    mats['neighbours'] = (torch.from_numpy(nb).to(gpu_device), None, torch.from_numpy(nb_n).to(gpu_device))
+    top = {kind: cdo.matrix_to_dict(m[0].cpu().numpy(), m[-1].cpu().numpy()) for kind, m in mats.items()}
+    aid = torch.from_numpy(ev.aid.astype(np.int32)).to(gpu_device)
+    typ = torch.from_numpy(ev.type).to(gpu_device)
+    off = torch.from_numpy(ev.sess_off).to(gpu_device)
+    S = ev.n_sessions
+    # ground truth of the type: 0 - 3 aids per session (clicks hold one), some of them session aids / candidates
+    lab = [sorted(set(rng.integers(0, ev.n_aids, int(rng.integers(0, 4))).tolist() + ([int(ev.aid[ev.sess_off[s]])] if s % 3 == 0 else [])))
+           for s in range(S)]
+    l_off = torch.from_numpy(np.r_[0, np.cumsum([len(x) for x in lab])].astype(np.int64)).to(gpu_device)
+    l_aid = torch.from_numpy(np.array([a for x in lab for a in x], dtype=np.int32)).to(gpu_device)
+    sess_ids = torch.arange(S, device=gpu_device, dtype=torch.int64) * 7 + 11_000_000
+    for recipe, orecipe, labels in ((cd.INFERENCE_CLICK_RECIPE, cdo.INFERENCE_CLICK_RECIPE, (l_off, l_aid)),
+                                    (cd.INFERENCE_CART_RECIPE, cdo.INFERENCE_CART_RECIPE, None)):
+        cand, cnt, n = cd.candidate_lookup(aid, typ, off, mats, recipe, n_common=100)
+        tab = cd.ranker_table(aid, off, cand, cnt, n, labels=labels, session_ids=sess_ids)
+        ro = tab['row_off'].cpu().numpy()
+        t_s, t_c, t_w = tab['session'].cpu().numpy(), tab['candidates'].cpu().numpy(), tab['candidate_scores'].cpu().numpy()
+        t_l = None if labels is None else tab['candidate_labels'].cpu().numpy()
+        want = cdo.all_candidates(ev.aid, ev.type, ev.sess_off, top, orecipe, 100)
+        rows = 0
+        for s, (wa, wc) in enumerate(want):
+            lo, hi = ev.sess_off[s], ev.sess_off[s + 1]
+            pred, sc, lb = cdo.session_ranker_rows(ev.aid[lo:hi], wa, wc, None if labels is None else lab[s])
+            a, b = ro[s], ro[s + 1]
+            assert b - a == len(pred), s
+            assert t_c[a:b].tolist() == pred and t_w[a:b].tolist() == [float(v) for v in sc] and (t_s[a:b] == 11_000_000 + 7 * s).all(), s
+            if labels is not None:
+                assert t_l[a:b].tolist() == lb, s
+            rows += len(pred)
+        assert rows == len(t_c) and (labels is None or t_l.sum() > 0)
+        # interaction features of the table
+        row, sf, af = ife.interaction_features_rows(aid, typ, off, tab, ev.n_aids)
+        got = ife.table_to_frame(tab, row, sf, af)
+        got['session'] = (got['session'] - 11_000_000) // 7
+        s_idx = np.repeat(np.arange(S), np.diff(ro))
+        wantf = io.interaction_features(pd.DataFrame({'session': s_idx.astype(np.int32), 'candidates': t_c, 'candidate_scores': t_w}), ev.to_frame())
+        key = ['session', 'candidates']
+        got = got.sort_values(key).reset_index(drop=True)
+        wantf = wantf.sort_values(key).reset_index(drop=True)
+        assert len(got) == len(wantf) and (got[key].to_numpy() == wantf[key].to_numpy()).all()
+        for col in ife.ROW_COLUMNS + ife.SESSION_COLUMNS + ife.AID_COLUMNS:
+            g, w = got[col].to_numpy().astype(np.float64), wantf[col].to_numpy().astype(np.float64)
+            assert np.array_equal(np.isnan(g), np.isnan(w)), col
+            ok = ~np.isnan(w)
+            if col.endswith(('_sum', '_max', '_min', 'occurrence_count', 'cumcount_last')) and 'score' not in col:
+                assert np.array_equal(g[ok], w[ok]), col
+            else:
+                np.testing.assert_allclose(g[ok], w[ok].astype(np.float32), rtol=1e-5, atol=1e-6, err_msg=col)
+        assert (got['session_candidate_occurrence_count'] > 0).any()          # the session's own aids are rows of this table
+    # empty input
+    e = torch.zeros(0, dtype=torch.int32, device=gpu_device)
+    tab = cd.ranker_table(e, torch.zeros(1, dtype=torch.int64, device=gpu_device), torch.zeros((0, 100), dtype=torch.int32, device=gpu_device),
+                          torch.zeros((0, 100), dtype=torch.int32, device=gpu_device), e)
+    assert tab['candidates'].numel() == 0 and tab['row_off'].tolist() == [0]
+
+
 def test_recency_branch_predictions_with_neighbour_and_list_bumps(gpu_device):
     """The `recency_weight` branch of the standalone model (`src/covisitation/inference.py:143-199`, sessions with at least
     20 unique aids): recency-weighted Counters + 0.05 / 0.05 / 0.15 for the neighbours of the last aid and for every entry
