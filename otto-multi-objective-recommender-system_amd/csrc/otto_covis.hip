@@ -916,8 +916,19 @@ __global__ void k_hist_runs(const uint32_t* run_x, const uint64_t* run_desc, int
 // cursor bump per (chunk, bucket)), then one workgroup per bucket counts and places its runs with LDS atomics
 // only; a bucket's slice of run_start / sorted_desc is a window of a few hundred KB, so those writes combine in L2.
 constexpr int BKT_THREADS = 1024;
-constexpr int BKT_CHUNK = 16384;                      // run slots per pass-1 work item
-constexpr int BKT_MAX_NB = 4096;                      // buckets (LDS histogram of pass 1)
+constexpr int BKT_CHUNK = 16384;                      // run slots per pass-1 work item (staged in LDS: 128 KB of 8-byte records)
+constexpr int BKT_MAX_NB = 2048;                      // buckets (LDS histogram / offsets / cursors of pass 1)
+constexpr int BKT_MAX_SH = 13;                        // aids per bucket <= 8192: 13 bits of the bucketed record, 96 KB of LDS in k_bkt_fused
+
+// Bucketed run record (8 bytes; the bucket is implied by the position): len - 1 (5 bits; only non-empty runs travel) |
+// first record slot << 5 (40 bits) | sp << 45 (6 bits) | (aid_x & (bucket size - 1)) << 51 (13 bits)
+__device__ __forceinline__ uint64_t bkt_pack(uint64_t d, uint32_t xlow) {
+    return (uint64_t)(desc_len(d) - 1u) | (desc_slot(d) << 5) | ((uint64_t)desc_sp(d) << 45) | ((uint64_t)xlow << 51);
+}
+__device__ __forceinline__ uint64_t bkt_desc(uint64_t r) {
+    return make_desc((r >> 5) & DESC_SLOT_MASK, ((uint32_t)r & 31u) + 1u, (uint32_t)(r >> 45) & 63u);
+}
+__device__ __forceinline__ uint32_t bkt_xlow(uint64_t r) { return (uint32_t)(r >> 51); }
 
 struct BktArgs {
     const uint32_t* run_x;
@@ -929,29 +940,36 @@ struct BktArgs {
     uint32_t* bcnt_blk;            // [nb][split grid] runs per (bucket, split workgroup)
     const uint64_t* bscan;         // [nb * split grid + 1] its bucket-major exclusive scan: bucket b starts at bscan[b * bstride]
     uint32_t bstride;              // = split grid
-    ulonglong2* tmp;               // bucketed runs {desc, aid_x}
+    uint64_t* tmp;                 // bucketed run records
     uint64_t* cnt64;
     const uint64_t* run_start;
     uint64_t* sorted_desc;
 };
 
 // Split without global atomics: workgroup w always takes the same range of consecutive chunks, so the count pass leaves ONE counter
-// per (bucket, workgroup) and their bucket-major scan is every workgroup's private, contiguous piece of every bucket:
-// the scatter pass keeps running cursors in LDS and needs neither a per-chunk histogram nor a cursor bump.
+// per (bucket, workgroup) and their bucket-major scan is every workgroup's private, contiguous piece of every bucket.
 //   count  : s_cnt = histogram over all the workgroup's chunks (only run_x is read: empty runs carry RUN_X_EMPTY)
-//   scatter: s_cnt[b] = the workgroup's next position in bucket b; one returning LDS atomic per run
+//   scatter: a chunk of 16 k run slots is SORTED BY BUCKET IN LDS (histogram with returning LDS atomics = rank inside the
+//            (chunk, bucket) piece, block scan = the piece's place in the stage) and each piece is copied by one wave to the
+//            workgroup's cursor of that bucket: consecutive lanes, consecutive addresses, pieces of ~70 records (~600 bytes)
+//            at OTTO shape. (Round 2 stored every run straight to its cursor, 16 bytes each: a 32-byte sector of HBM
+//            traffic per run, 4.1 GB written for 2.05 GB.)
 template <bool SCATTER>
 __global__ __launch_bounds__(BKT_THREADS) void k_bkt_split(BktArgs a) {
-    __shared__ uint32_t s_cnt[BKT_MAX_NB];
+    __shared__ uint32_t s_cnt[BKT_MAX_NB];                       // count: histogram over the chunks; scatter: the workgroup's cursors
+    __shared__ uint32_t s_hist[SCATTER ? BKT_MAX_NB : 1];        // runs of this chunk per bucket
+    __shared__ uint32_t s_loc[SCATTER ? BKT_MAX_NB : 1];         // first stage position of the bucket's piece
+    __shared__ uint64_t s_stage[SCATTER ? BKT_CHUNK : 1];
+    __shared__ uint32_t s_sc[BKT_THREADS / 64 + 1];
     const int64_t n_chunks = (a.n_slots + BKT_CHUNK - 1) / BKT_CHUNK;
     constexpr int PER = BKT_CHUNK / BKT_THREADS;
+    constexpr int BPT = BKT_MAX_NB / BKT_THREADS;                // buckets per thread in the scan
     for (uint32_t b = threadIdx.x; b < a.nb; b += BKT_THREADS)
         s_cnt[b] = SCATTER ? (uint32_t)a.bscan[(size_t)b * gridDim.x + blockIdx.x] : 0u;      // absolute position (run slots < 2^32)
     __syncthreads();
-    // consecutive chunks per workgroup: its pieces of a bucket are written back to back in time, so the 16-byte stores of
-    // neighbouring chunks complete each other's cache lines in L2
     const int64_t per_wg = (n_chunks + gridDim.x - 1) / gridDim.x;
     const int64_t ch_end = min(n_chunks, (int64_t)(blockIdx.x + 1) * per_wg);
+    const uint32_t xmask = (1u << a.sh) - 1u;
     for (int64_t ch = (int64_t)blockIdx.x * per_wg; ch < ch_end; ++ch) {
         const int64_t i0 = ch * BKT_CHUNK + threadIdx.x;
         uint32_t xs[PER];
@@ -971,16 +989,50 @@ __global__ __launch_bounds__(BKT_THREADS) void k_bkt_split(BktArgs a) {
 #pragma unroll
             for (int u = 0; u < PER; ++u)
                 if (xs[u] != RUN_X_EMPTY) atomicAdd(&s_cnt[xs[u] >> a.sh], 1u);
-        } else {
+            continue;
+        }
+        for (uint32_t b = threadIdx.x; b < a.nb; b += BKT_THREADS) s_hist[SCATTER ? b : 0] = 0;
+        __syncthreads();
+        uint32_t rk[PER];
 #pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                if (xs[u] != RUN_X_EMPTY) {
-                    const uint32_t b = xs[u] >> a.sh;
-                    const uint32_t pos = atomicAdd(&s_cnt[b], 1u);
-                    a.tmp[pos] = make_ulonglong2(ds[u], (unsigned long long)xs[u]);     // one 16-byte store per run
-                }
+        for (int u = 0; u < PER; ++u) {
+            rk[u] = 0;
+            if (xs[u] != RUN_X_EMPTY) rk[u] = atomicAdd(&s_hist[SCATTER ? xs[u] >> a.sh : 0], 1u);
+        }
+        __syncthreads();
+        {   // exclusive scan of the chunk's histogram: thread t owns buckets t * BPT .. + BPT
+            uint32_t h[BPT], mine = 0;
+#pragma unroll
+            for (int q = 0; q < BPT; ++q) {
+                const uint32_t b = threadIdx.x * BPT + q;
+                h[q] = b < a.nb ? s_hist[SCATTER ? b : 0] : 0u;
+                mine += h[q];
+            }
+            uint32_t tot;
+            uint32_t run = block_excl_scan<uint32_t, BKT_THREADS>(mine, s_sc, &tot);
+#pragma unroll
+            for (int q = 0; q < BPT; ++q) {
+                const uint32_t b = threadIdx.x * BPT + q;
+                if (b < a.nb) s_loc[SCATTER ? b : 0] = run;
+                run += h[q];
             }
         }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if (xs[u] != RUN_X_EMPTY)
+                s_stage[SCATTER ? s_loc[SCATTER ? xs[u] >> a.sh : 0] + rk[u] : 0] = bkt_pack(ds[SCATTER ? u : 0], xs[u] & xmask);
+        __syncthreads();
+        // one wave per piece: stage -> the workgroup's cursor of the bucket
+        const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        for (uint32_t b = w; b < a.nb; b += BKT_THREADS / 64) {
+            const uint32_t n = s_hist[SCATTER ? b : 0];
+            if (n == 0) continue;
+            const uint32_t src = s_loc[SCATTER ? b : 0], dst = s_cnt[b];
+            for (uint32_t l = lane; l < n; l += 64u) a.tmp[dst + l] = s_stage[SCATTER ? src + l : 0];
+            if (lane == 0) s_cnt[b] = dst + n;
+        }
+        __syncthreads();
     }
     if (!SCATTER) {
         __syncthreads();
@@ -988,9 +1040,9 @@ __global__ __launch_bounds__(BKT_THREADS) void k_bkt_split(BktArgs a) {
     }
 }
 
-// count + scan + place of one bucket in ONE workgroup (replaces k_bkt_local<false>, the device-wide scan of the run counts
-// and k_bkt_local<true>): the first run of aid x is the bucket's first run (bstart[b], known from the split) + the runs of
-// the bucket's aids before x, so the prefix is a block scan in LDS; the second walk over the bucket's runs hits L2.
+// count + scan + place of one bucket in ONE workgroup: the first run of aid x is the bucket's first run (bstart[b], known from
+// the split) + the runs of the bucket's aids before x, so the prefix is a block scan in LDS; the second walk over the bucket's
+// runs (4.6 MB of 8-byte records at OTTO shape) is served by the Infinity Cache.
 __global__ __launch_bounds__(BKT_THREADS) void k_bkt_fused(BktArgs a, uint64_t* run_start_out) {
     extern __shared__ unsigned long long s_dyn[];          // [1 << sh]: runs << 36 | records, then start positions
     uint32_t* s_cur = reinterpret_cast<uint32_t*>(s_dyn + ((size_t)1 << a.sh));   // [1 << sh] cursors
@@ -1003,19 +1055,15 @@ __global__ __launch_bounds__(BKT_THREADS) void k_bkt_fused(BktArgs a, uint64_t* 
         __syncthreads();
         const uint64_t e0 = a.bscan[(size_t)b * a.bstride], e1 = a.bscan[(size_t)(b + 1) * a.bstride];
         for (uint64_t i0 = e0 + threadIdx.x; i0 < e1; i0 += 4 * BKT_THREADS) {
-            uint32_t xl[4];
-            uint64_t d[4];
+            uint64_t r[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint64_t i = i0 + (uint64_t)u * BKT_THREADS;
-                ulonglong2 r = make_ulonglong2(0ull, 0ull);
-                if (i < e1) r = a.tmp[i];
-                d[u] = r.x;
-                xl[u] = (uint32_t)r.y - x0;
+                r[u] = i < e1 ? a.tmp[i] : ~0ull;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (d[u]) atomicAdd(&s_dyn[xl[u]], (1ull << CNT_REC_BITS) | desc_pairs(d[u]));
+                if (r[u] != ~0ull) atomicAdd(&s_dyn[bkt_xlow(r[u])], (1ull << CNT_REC_BITS) | desc_pairs(bkt_desc(r[u])));
         }
         __syncthreads();
         // counts out, exclusive scan of the run counts over the bucket's aids (thread t: aids t * per .. + per)
@@ -1042,19 +1090,15 @@ __global__ __launch_bounds__(BKT_THREADS) void k_bkt_fused(BktArgs a, uint64_t* 
         if (b == a.nb - 1 && threadIdx.x == 0) run_start_out[a.n_aids] = e1;
         __syncthreads();
         for (uint64_t i0 = e0 + threadIdx.x; i0 < e1; i0 += 4 * BKT_THREADS) {
-            uint32_t xl[4];
-            uint64_t d[4];
+            uint64_t r[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint64_t i = i0 + (uint64_t)u * BKT_THREADS;
-                ulonglong2 r = make_ulonglong2(0ull, 0ull);
-                if (i < e1) r = a.tmp[i];
-                d[u] = r.x;
-                xl[u] = (uint32_t)r.y - x0;
+                r[u] = i < e1 ? a.tmp[i] : ~0ull;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (d[u]) a.sorted_desc[s_dyn[xl[u]] + atomicAdd(&s_cur[xl[u]], 1u)] = d[u];
+                if (r[u] != ~0ull) a.sorted_desc[s_dyn[bkt_xlow(r[u])] + atomicAdd(&s_cur[bkt_xlow(r[u])], 1u)] = bkt_desc(r[u]);
         }
         __syncthreads();
     }
@@ -2564,16 +2608,17 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             uint32_t hpos = 0, lpos = H;
 #pragma unroll
             for (int q = 0; q < NITMAX; ++q) {
-                if (q >= nq) break;
-                const bool v = (vv >> q) & 1u, h = (hv >> q) & 1u;
-                const uint64_t mh = __ballot(h), ml = __ballot(v && !h);
-                if (v) {
-                    const uint64_t m = h ? mh : ml;
-                    const uint32_t pos = (h ? hpos : lpos) + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    s_occ[NW > 1 ? wid * RCAP + pos : 0] = (uint16_t)ent[q];
+                if (q < nq) {
+                    const bool v = (vv >> q) & 1u, h = (hv >> q) & 1u;
+                    const uint64_t mh = __ballot(h), ml = __ballot(v && !h);
+                    if (v) {
+                        const uint64_t m = h ? mh : ml;
+                        const uint32_t pos = (h ? hpos : lpos) + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        s_occ[NW > 1 ? wid * RCAP + pos : 0] = (uint16_t)ent[q];
+                    }
+                    hpos += (uint32_t)__popcll(mh);
+                    lpos += (uint32_t)__popcll(ml);
                 }
-                hpos += (uint32_t)__popcll(mh);
-                lpos += (uint32_t)__popcll(ml);
             }
             if (lane == 0) s_hcnt[NW > 1 ? wid : 0] = H;
             wave_lds_sync();
@@ -2695,7 +2740,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             //      a third of their instructions.
             constexpr bool SH = HOT && NW <= 4;
             constexpr int SHR = 4;
-            if (SH && hot) {
+            if (SH && hot && a.hot_ok >= 2) {
                 __syncthreads();                             // s_hcnt of every wave
                 uint32_t pre[NW + 1];
                 pre[0] = 0;
@@ -3231,7 +3276,8 @@ struct otto_covis_ctx {
     int items_allow_packed = -1;   // layout rule the L item list was built with (-1: not built)
     DevBuf tau_w, tau_y;           // threshold guesses of partitioned heavy aids (per reduce pass)
     int guess = 1;                 // option "guess": single-pass top-k from a sibling partition's threshold
-    int hot = 1;                   // option "hot": top-k walks of the multi-wave bins over the heavy keys only (A/B)
+    int hot = 2;                   // option "hot": 1 = top-k walks of the multi-wave bins over the heavy keys only, 2 = + single-wave
+                                   // selection when the heavy keys are few (M bin), 0 = off (A/B)
     DevBuf exp_run_pos, exp_rec_pos, exp_totals;
     uint64_t exp_n_runs[64] = {0}, exp_n_recs[64] = {0};
     int exp_planned = 0;
@@ -3556,9 +3602,11 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
     while ((1ull << aid_bits) < (uint64_t)n_aids) ++aid_bits;
     BktArgs ba;
     memset(&ba, 0, sizeof ba);
-    ba.sh = aid_bits > 22 ? aid_bits - 12 : 10;
+    // ~256 buckets where the aid space allows it: the pieces a 16 k-run chunk sends to one bucket are then ~64 runs long (full
+    // cache lines); buckets of at most 2^13 aids (the record's 13 bits, 96 KB of LDS in k_bkt_fused)
+    ba.sh = aid_bits - 8 < 10 ? 10 : (aid_bits - 8 > BKT_MAX_SH ? BKT_MAX_SH : aid_bits - 8);
     ba.nb = (uint32_t)(((uint64_t)n_aids + (1ull << ba.sh) - 1) >> ba.sh);
-    const bool bucketed = c->bucket_index && n_slots > 0 && n_slots < (1ll << 32) && ba.nb <= (uint32_t)BKT_MAX_NB && ba.sh <= 12;   // <= 48 KB of LDS per bucket
+    const bool bucketed = c->bucket_index && n_slots > 0 && n_slots < (1ll << 32) && ba.nb <= (uint32_t)BKT_MAX_NB;
     if (bucketed) {
         ba.run_x = c->run_x.as<uint32_t>(); ba.run_desc = c->run_desc.as<uint64_t>();
         ba.n_slots = n_slots; ba.n_aids = n_aids;
@@ -3576,8 +3624,8 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
         OTTO_HIP(hipGetLastError());
         OTTO_TRY(device_scan(BktCount{ba.bcnt_blk}, n_cells, c->bstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
         // non-empty runs <= run slots: the buffers are sized by the bound, so the split needs no host round trip
-        OTTO_TRY(c->tmp_runs.ensure((size_t)n_slots * 16, 0, s));
-        ba.tmp = c->tmp_runs.as<ulonglong2>();
+        OTTO_TRY(c->tmp_runs.ensure((size_t)n_slots * 8, 0, s));
+        ba.tmp = c->tmp_runs.as<uint64_t>();
         k_bkt_split<true><<<sgrid, BKT_THREADS, 0, s>>>(ba);
         OTTO_HIP(hipGetLastError());
         ba.cnt64 = c->cnt64.as<uint64_t>();
@@ -3585,6 +3633,7 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
         // the split left every bucket's runs contiguous: counting / scanning / placing is one launch
         OTTO_TRY(c->sorted_desc.ensure((size_t)n_slots * 8, 0, s));
         ba.sorted_desc = c->sorted_desc.as<uint64_t>();
+        OTTO_HIP(hipFuncSetAttribute((const void*)k_bkt_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 12 << BKT_MAX_SH));
         k_bkt_fused<<<lgrid, BKT_THREADS, (size_t)12 << ba.sh, s>>>(ba, c->run_start.as<uint64_t>());
         OTTO_HIP(hipGetLastError());
     } else if (n_slots) {
@@ -3856,7 +3905,7 @@ extern "C" int otto_covis_finalize(otto_covis_ctx* c, int group, int k, uint32_t
         // a key of two records and below a key of one cart / order record
         a.hot_ok = 0;
         if (group == OTTO_COVIS_GROUP_TYPE && c->hot) {
-            a.hot_ok = 1;
+            a.hot_ok = c->hot;
             for (int j = 0; j < a.nk; ++j) {
                 const uint32_t c0 = a.coef[j][0], c1 = a.coef[j][1], c2 = a.coef[j][2];
                 const uint32_t mn = c0 < c1 ? (c0 < c2 ? c0 : c2) : (c1 < c2 ? c1 : c2);
@@ -3922,7 +3971,7 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
     if (strcmp(name, "bucket_index") == 0) { c->bucket_index = value != 0; return 0; }
     if (strcmp(name, "guess") == 0) { c->guess = value != 0; return 0; }           // threshold guessing on/off (A/B)
     if (strcmp(name, "fused") == 0) { c->fused = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return 0; }   // 2 component lists, 1 fused register rows, 0 class-sorted kernels (A/B)
-    if (strcmp(name, "hot") == 0) { c->hot = value != 0; return 0; }
+    if (strcmp(name, "hot") == 0) { c->hot = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return 0; }
     if (strcmp(name, "fast_path") == 0) { c->fast_path = value != 0; return 0; }   // gap-free window kernel on/off (A/B)
     if (strcmp(name, "part_sized") == 0) { c->part_sized = value != 0; return 0; }   // A/B: counted buckets only
     if (strcmp(name, "partition") == 0) {
