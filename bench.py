@@ -82,15 +82,23 @@ def algorithmic_bytes(st, k, nk):
 TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'round3', 'traffic.json')
 
 
-def source_hash():
-    """sha256 over the kernel sources the traffic numbers belong to (csrc/*.hip, csrc/*.h, include/*.h)."""
-    import glob
+SOURCES = {   # the files a kernel family is compiled from: its traffic numbers hold while THESE are unchanged
+    'covis': ('csrc/otto_covis.hip', 'csrc/common.h', 'csrc/topk.h', 'csrc/scan.h', 'include/otto_covis.h'),
+    'mf': ('csrc/otto_mf.hip', 'csrc/common.h', 'include/otto_mf.h'),
+}
+
+
+def source_hash(family=None):
+    """sha256 over the kernel sources the traffic numbers of a kernel family belong to ({family: hash} without argument)."""
     import hashlib
+    if family is None:
+        return {f: source_hash(f) for f in SOURCES}
     h = hashlib.sha256()
-    pkg = os.path.join(ROOT, 'otto-multi-objective-recommender-system_amd', 'csrc')
-    for f in sorted(glob.glob(os.path.join(pkg, '*.hip')) + glob.glob(os.path.join(pkg, '*.h')) + glob.glob(os.path.join(ROOT, 'include', '*.h'))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, 'rb').read())
+    for rel in SOURCES[family]:
+        path = os.path.join(ROOT, 'include', os.path.basename(rel)) if rel.startswith('include/') else \
+            os.path.join(ROOT, 'otto-multi-objective-recommender-system_amd', rel)
+        h.update(os.path.basename(rel).encode())
+        h.update(open(path, 'rb').read())
     return h.hexdigest()
 
 
@@ -106,7 +114,8 @@ def pmc_traffic(names, full_otto):
         doc = json.load(open(TRAFFIC_FILE))
     except Exception:
         return None
-    if doc.get('source_hash') != source_hash():
+    family = 'mf' if any(n.startswith(('k_bpr', 'k_rmf', 'k_mf', 'k_score')) for n in names) else 'covis'
+    if not isinstance(doc.get('source_hash'), dict) or doc['source_hash'].get(family) != source_hash(family):
         return None
     tot = sum(v['traffic_bytes_per_launch'] for k, v in doc['kernels'].items() if any(n in k for n in names))
     return int(tot) if tot else None

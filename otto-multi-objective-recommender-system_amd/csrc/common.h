@@ -75,6 +75,20 @@ struct DevBuf {
 // ---------------------------------------------------------------------------
 constexpr int WAVE = 64;
 
+// Scratch that outlives a call of the context-free entry points (error words, scan partials, per-session offsets): one
+// growing buffer per (device, slot), kept until the process exits. A hipMalloc / hipFree pair per call would synchronise the
+// device and the caller's stream on every call. Not thread-safe, like the contexts: one slot per entry point family, calls
+// of one family on one device must not overlap.
+enum { SCRATCH_CAND = 0, SCRATCH_RECENCY, SCRATCH_RECENCY_PRED, SCRATCH_EVENTS, SCRATCH_PAIRS_A, SCRATCH_PAIRS_B, SCRATCH_SLOTS };
+inline int device_scratch(int slot, size_t bytes, void** out, hipStream_t s) {
+    static DevBuf bufs[16][SCRATCH_SLOTS];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { set_error("device_scratch: no current device"); return -5; }
+    const int rc = bufs[dev][slot].ensure(bytes < 256 ? 256 : bytes, 0, s);
+    *out = bufs[dev][slot].p;
+    return rc;
+}
+
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 
 template <typename T>

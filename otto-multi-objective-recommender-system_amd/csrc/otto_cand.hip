@@ -64,7 +64,7 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
     __shared__ uint64_t s_lb[CD_THREADS];
     __shared__ uint64_t s_ex[CD_EXCAP];
     __shared__ uint64_t s_thr;
-    __shared__ uint32_t s_nex, s_more, s_ovf, s_nfresh, s_sp, s_scan[CD_NW + 1], s_keep[2];
+    __shared__ uint32_t s_nex, s_more, s_ovf, s_nfresh, s_sp, s_scan[CD_NW + 1], s_keep[2], s_maxlen;
     __shared__ uint32_t s_stack[CD_STACK];            // hash partitions still to do: id | level << 24
 
     const int tid = threadIdx.x, wid = tid >> 6;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
         // ---- A ----------------------------------------------------------------------------------------
         for (int i = tid; i < n; i += CD_THREADS) { s_aid[i] = a.aid[lo + i]; s_ty[i] = a.type[lo + i]; }
         if (tid < 3 || tid == 4) s_nsrc[tid] = 0;
-        if (tid == 3) s_nsrc[3] = n > 0 ? 1u : 0u;
+        if (tid == 3) { s_nsrc[3] = n > 0 ? 1u : 0u; s_maxlen = 0; }
         if (a.self_count)
             for (int i = tid; i < n; i += CD_THREADS) a.self_count[lo + i] = 0;
         for (int i = tid; i < NC; i += CD_THREADS) s_sel[i] = 0;
@@ -145,6 +145,7 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
             uint32_t tot;
             const uint32_t off = block_excl_scan<uint32_t, CD_THREADS>(len, s_scan, &tot);
             if (q < Q) s_base[q] = (running + off) | (len << 24);
+            if (len > 32u) atomicMax(&s_maxlen, len);            // neighbour lists (45 entries): a second sweep of the gather
             running += tot;
         }
         const uint32_t TOT = running;
@@ -190,35 +191,61 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
             for (int i = tid; i < Teff; i += CD_THREADS) { s_tab[i] = CD_EMPTY; s_fp[i] = 0xFFFFFFFFu; }
             __syncthreads();
             const int hw = tid >> 5, l = tid & 31;
-            for (uint32_t q = hw; q < Q; q += CD_THREADS / 32) {
-                if (s_ovf) break;                             // the partition is being split: its table is not used
-                const uint32_t b = s_base[q];
-                const uint32_t len = b >> 24, base = b & 0xFFFFFFu;
-                for (uint32_t l2 = (uint32_t)l; l2 < len; l2 += 32u) {      // lists longer than 32 (neighbour lists): two rounds
-                    int t = 0;
+            // One half-wave per list, GU lists in flight per half-wave: the list rows come from global memory (L2 at best) and a
+            // half-wave that waits for one row at a time spends the gather in load latency (a long session concatenates several
+            // hundred lists: 20+ dependent round trips per half-wave); the inserts of a batch start when its rows have arrived.
+            constexpr int GU = 4;
+            constexpr uint32_t HWS = CD_THREADS / 32;
+            const uint32_t sweeps = s_maxlen > 32u ? (s_maxlen + 31u) / 32u : 1u;      // lists longer than 32 (neighbour lists): more sweeps
+            for (uint32_t sw = 0; sw < sweeps; ++sw) {
+                const uint32_t l2 = (uint32_t)l + 32u * sw;
+                for (uint32_t q0 = hw; q0 < Q; q0 += HWS * GU) {
+                    if (s_ovf) break;                             // the partition is being split: its table is not used
+                    uint32_t yv[GU], pv[GU];
+                    bool ok[GU];
 #pragma unroll
-                    for (int u = 1; u < OTTO_CAND_MAX_TERMS; ++u) t += (q >= tstart[u]) ? 1 : 0;
-                    const uint32_t x = src_aid(a.p.term_source[t], q - tstart[t]);
-                    const int m = a.p.term_matrix[t];
-                    const uint32_t y = (uint32_t)a.p.d_mat_y[m][(size_t)x * (a.p.mat_k[m] > 0 ? a.p.mat_k[m] : K) + l2];
-                    const uint32_t h = y * 0x9E3779B1u;
-                    if (lgR == 0 || ((h >> (32 - lt - lgR)) & (R - 1u)) == part) {
-                        uint32_t slot = h >> (32 - lt);
-                        bool placed = false;
-                        for (int probe = 0; probe < Teff; ++probe) {
-                            // CAS first: a new aid goes in together with its first count
-                            const unsigned long long old = atomicCAS(&s_tab[slot], (unsigned long long)CD_EMPTY, ((unsigned long long)y << 32) | 1ull);
-                            const bool fresh = old == CD_EMPTY;
-                            if (fresh || (uint32_t)(old >> 32) == y) {
-                                if (!fresh) atomicAdd(&s_tab[slot], 1ull);
-                                else if (TOT > (uint32_t)CD_CAP && atomicAdd(&s_nfresh, 1u) >= (uint32_t)CD_CAP) s_ovf = 1;   // too full to probe cheaply
-                                atomicMin(&s_fp[slot], base + l2);
-                                placed = true;
-                                break;
+                    for (int u = 0; u < GU; ++u) {
+                        const uint32_t q = q0 + (uint32_t)u * HWS;
+                        ok[u] = false;
+                        yv[u] = pv[u] = 0;
+                        if (q < Q) {
+                            const uint32_t b = s_base[q];
+                            const uint32_t len = b >> 24;
+                            if (l2 < len) {
+                                int t = 0;
+#pragma unroll
+                                for (int v = 1; v < OTTO_CAND_MAX_TERMS; ++v) t += (q >= tstart[v]) ? 1 : 0;
+                                const uint32_t x = src_aid(a.p.term_source[t], q - tstart[t]);
+                                const int m = a.p.term_matrix[t];
+                                yv[u] = (uint32_t)a.p.d_mat_y[m][(size_t)x * (a.p.mat_k[m] > 0 ? a.p.mat_k[m] : K) + l2];
+                                pv[u] = (b & 0xFFFFFFu) + l2;
+                                ok[u] = true;
                             }
-                            slot = (slot + 1) & (uint32_t)(Teff - 1);
                         }
-                        if (!placed) s_ovf = 1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < GU; ++u) {
+                        if (!ok[u]) continue;
+                        const uint32_t y = yv[u];
+                        const uint32_t h = y * 0x9E3779B1u;
+                        if (lgR == 0 || ((h >> (32 - lt - lgR)) & (R - 1u)) == part) {
+                            uint32_t slot = h >> (32 - lt);
+                            bool placed = false;
+                            for (int probe = 0; probe < Teff; ++probe) {
+                                // CAS first: a new aid goes in together with its first count
+                                const unsigned long long old = atomicCAS(&s_tab[slot], (unsigned long long)CD_EMPTY, ((unsigned long long)y << 32) | 1ull);
+                                const bool fresh = old == CD_EMPTY;
+                                if (fresh || (uint32_t)(old >> 32) == y) {
+                                    if (!fresh) atomicAdd(&s_tab[slot], 1ull);
+                                    else if (TOT > (uint32_t)CD_CAP && atomicAdd(&s_nfresh, 1u) >= (uint32_t)CD_CAP) s_ovf = 1;   // too full to probe cheaply
+                                    atomicMin(&s_fp[slot], pv[u]);
+                                    placed = true;
+                                    break;
+                                }
+                                slot = (slot + 1) & (uint32_t)(Teff - 1);
+                            }
+                            if (!placed) s_ovf = 1;
+                        }
                     }
                 }
             }
@@ -707,7 +734,7 @@ extern "C" int otto_recency_candidates(const otto_recency_params* p, const uint3
     OTTO_REQUIRE(d_aid && d_type, "null event arrays");
     hipStream_t s = (hipStream_t)stream;
     uint32_t* d_err = nullptr;
-    OTTO_HIP(hipMalloc(&d_err, 4));
+    OTTO_TRY(device_scratch(SCRATCH_RECENCY, 4, (void**)&d_err, s));
     OTTO_HIP(hipMemsetAsync(d_err, 0, 4, s));
     RecencyArgs a;
     memset(&a, 0, sizeof a);
@@ -722,7 +749,6 @@ extern "C" int otto_recency_candidates(const otto_recency_params* p, const uint3
     uint32_t h_err = 0;
     if (le == hipSuccess) le = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, s);
     if (le == hipSuccess) le = hipStreamSynchronize(s);
-    (void)hipFree(d_err);
     if (le != hipSuccess) { set_error("otto_recency_candidates: %s", hipGetErrorString(le)); return -5; }
     OTTO_REQUIRE(h_err == 0, "%u session(s) longer than %d events", h_err, OTTO_CAND_MAX_SESSION);
     return 0;
@@ -747,7 +773,7 @@ static int cand_lookup(const otto_cand_params* p, const uint32_t* d_aid, const u
     OTTO_REQUIRE(d_aid && d_type, "null event arrays");
     hipStream_t s = (hipStream_t)stream;
     uint32_t* d_err = nullptr;
-    OTTO_HIP(hipMalloc(&d_err, 4));
+    OTTO_TRY(device_scratch(SCRATCH_CAND, 4, (void**)&d_err, s));
     OTTO_HIP(hipMemsetAsync(d_err, 0, 4, s));
     CandArgs a;
     memset(&a, 0, sizeof a);
@@ -765,9 +791,11 @@ static int cand_lookup(const otto_cand_params* p, const uint32_t* d_aid, const u
     uint32_t err = 0;
     hipError_t ce = hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s);
     hipError_t se = hipStreamSynchronize(s);
-    (void)hipFree(d_err);
     OTTO_REQUIRE(le == hipSuccess && ce == hipSuccess && se == hipSuccess, "k_cand failed: %s", hipGetErrorString(le != hipSuccess ? le : (ce != hipSuccess ? ce : se)));
-    OTTO_REQUIRE(err == 0, "%u session(s) longer than %d events", err, OTTO_CAND_MAX_SESSION);
+    // low half: sessions over the length limit; high half: partitions that could not be split any further
+    OTTO_REQUIRE((err & 0xFFFFu) == 0, "%u session(s) longer than %d events", err & 0xFFFFu, OTTO_CAND_MAX_SESSION);
+    OTTO_REQUIRE((err >> 16) == 0, "%u hash partition(s) of the candidate table could not be split (more than %d stacked partitions or no hash bits left)",
+                 err >> 16, CD_STACK);
     return 0;
 }
 
@@ -795,7 +823,7 @@ extern "C" int otto_recency_predictions(const otto_recency_pred_params* p, const
     OTTO_REQUIRE(d_aid && d_type, "null event arrays");
     hipStream_t s = (hipStream_t)stream;
     uint32_t* d_err = nullptr;
-    OTTO_HIP(hipMalloc(&d_err, 4));
+    OTTO_TRY(device_scratch(SCRATCH_RECENCY_PRED, 4, (void**)&d_err, s));
     OTTO_HIP(hipMemsetAsync(d_err, 0, 4, s));
     RecPredArgs a;
     memset(&a, 0, sizeof a);
@@ -806,7 +834,6 @@ extern "C" int otto_recency_predictions(const otto_recency_pred_params* p, const
     uint32_t h_err = 0;
     if (le == hipSuccess) le = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, s);
     if (le == hipSuccess) le = hipStreamSynchronize(s);
-    (void)hipFree(d_err);
     if (le != hipSuccess) { set_error("otto_recency_predictions: %s", hipGetErrorString(le)); return -5; }
     OTTO_REQUIRE(h_err == 0, "%u session(s) longer than %d events", h_err, OTTO_CAND_MAX_SESSION);
     return 0;

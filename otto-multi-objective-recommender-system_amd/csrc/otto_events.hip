@@ -355,7 +355,7 @@ extern "C" int otto_events_type_from_strings(const void* d_offsets, int32_t offs
     OTTO_REQUIRE(d_offsets && d_bytes && d_out_type, "otto_events_type_from_strings: null argument");
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* bad = nullptr;
-    OTTO_HIP(hipMalloc(&bad, 8));
+    OTTO_TRY(device_scratch(SCRATCH_EVENTS, 8, (void**)&bad, s));
     OTTO_HIP(hipMemsetAsync(bad, 0, 8, s));
     const int grid = (int)((n + 255) / 256 < 256 * 16 ? (n + 255) / 256 : 256 * 16);
     if (offsets_are_64) k_type_strings<int64_t><<<grid, 256, 0, s>>>((const int64_t*)d_offsets, d_bytes, n, d_out_type, bad);
@@ -363,7 +363,6 @@ extern "C" int otto_events_type_from_strings(const void* d_offsets, int32_t offs
     unsigned long long hb = 0;
     hipError_t e = hipMemcpyAsync(&hb, bad, 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(bad);
     OTTO_HIP(e);
     OTTO_REQUIRE(hb == 0, "%llu event type strings are none of clicks / carts / orders", hb);
     return 0;

@@ -102,17 +102,16 @@ extern "C" int otto_pairs_raw_count(const int64_t* d_sess_off, int64_t n_sess, i
         return 0;
     }
     uint64_t *out = nullptr, *partial = nullptr;
-    OTTO_HIP(hipMalloc(&out, (size_t)(n_sess + 1) * 8));
-    hipError_t e = hipMalloc(&partial, scan_partial_bytes(n_sess));
-    int rc = e == hipSuccess ? device_scan(SelfJoinPairs{d_sess_off}, n_sess, out, partial, s) : -12;
+    OTTO_TRY(device_scratch(SCRATCH_PAIRS_A, (size_t)(n_sess + 1) * 8, (void**)&out, s));
+    OTTO_TRY(device_scratch(SCRATCH_PAIRS_B, scan_partial_bytes(n_sess), (void**)&partial, s));
+    hipError_t e = hipSuccess;
+    int rc = device_scan(SelfJoinPairs{d_sess_off}, n_sess, out, partial, s);
     uint64_t tot = 0;
     if (rc == 0) {
         e = hipMemcpyAsync(&tot, out + n_sess, 8, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) rc = -5;
     }
-    (void)hipFree(out);
-    (void)hipFree(partial);
     OTTO_REQUIRE(rc == 0, "otto_pairs_raw_count failed on the device");
     *h_raw = (int64_t)tot;
     return 0;
@@ -155,10 +154,10 @@ extern "C" int otto_pairs_time(const uint32_t* d_aid, const int32_t* d_ts, const
     otto_sort_ws_buffers(raw, d_ws, &key0, &val0, &scan_out, &scan_partial);
     // slot bases of the sessions: scan_out holds raw + 1 >= n_sess + 1 entries only if raw >= n_sess; otherwise a private buffer
     uint64_t* pair_off = nullptr;
-    OTTO_HIP(hipMalloc(&pair_off, (size_t)(n_sess + 1) * 8));
+    OTTO_TRY(device_scratch(SCRATCH_PAIRS_A, (size_t)(n_sess + 1) * 8, (void**)&pair_off, s));
     uint64_t* part = nullptr;
-    hipError_t e = hipMalloc(&part, scan_partial_bytes(n_sess));
-    int rc = e == hipSuccess ? device_scan(SelfJoinPairs{d_sess_off}, n_sess, pair_off, part, s) : -12;
+    OTTO_TRY(device_scratch(SCRATCH_PAIRS_B, scan_partial_bytes(n_sess), (void**)&part, s));
+    int rc = device_scan(SelfJoinPairs{d_sess_off}, n_sess, pair_off, part, s);
     int64_t n_events = 0;
     if (rc == 0 && (hipMemcpyAsync(&n_events, d_sess_off + n_sess, 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
                     hipStreamSynchronize(s) != hipSuccess)) rc = -5;
@@ -169,8 +168,6 @@ extern "C" int otto_pairs_time(const uint32_t* d_aid, const int32_t* d_ts, const
     }
     if (rc == 0) rc = finish_pairs(raw, d_ws, aggregation, d_out_x1, d_out_x2, d_out_target, h_n_rows, s);
     (void)hipStreamSynchronize(s);
-    (void)hipFree(pair_off);
-    (void)hipFree(part);
     OTTO_REQUIRE(rc == 0, "otto_pairs_time failed on the device (%d)", rc);
     return 0;
 }

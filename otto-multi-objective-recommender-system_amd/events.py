@@ -125,6 +125,11 @@ def frame_to_events_device(frame, device='cuda:0', n_aids=None, ts_unit='auto'):
         if is_str and n:
             import pyarrow as pa
             arr = typ if is_arrow else pa.array(typ.to_numpy(), type=pa.string())
+            if isinstance(arr, pa.ChunkedArray):
+                arr = arr.combine_chunks()
+            if arr.null_count:
+                # the device kernel reads offsets + bytes only: a null would be decoded from whatever bytes its offsets span
+                raise ValueError(f'type column holds {arr.null_count} null(s): event types must be clicks / carts / orders')
             big = str(arr.type) == 'large_string'
             bufs = arr.buffers()                 # [validity, offsets, data]
             off = np.frombuffer(bufs[1], dtype=np.int64 if big else np.int32)[arr.offset:arr.offset + n + 1]

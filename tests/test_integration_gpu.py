@@ -484,6 +484,8 @@ def test_device_ingest_rejects_unknown_type_strings_and_handles_empty(gpu_device
                        'ts': np.array([1_659_304_800_000, 1_659_304_801_000], dtype=np.uint64), 'type': ['clicks', 'wishlist']})
     with pytest.raises(_lib.OttoError, match='none of clicks'):
         frame_to_events_device(fr, device=gpu_device)
+    with pytest.raises(ValueError, match='null'):                         # the kernel never sees Arrow's validity bitmap
+        frame_to_events_device(fr.assign(type=['clicks', None]), device=gpu_device)
     empty = frame_to_events_device(fr.iloc[:0], device=gpu_device)
     assert empty.n_events == 0 and empty.n_sessions == 0
 
