@@ -147,6 +147,14 @@ def candidates_leg(data, dev, n_aids, train_sessions=3_000_000, sessions=1_800_0
     e0 = int(data['sess_off'][lo])
     vaid, vtyp = data['aid'][e0:].contiguous(), data['type'][e0:].contiguous()
     out = {}
+    # algorithmic bytes of the lookup: every list row the recipe concatenates (4 B per entry: sum over the source aids of a
+    # session of the lists' valid lengths, per term), the events (aid 4 + type 1), the [S, 100] candidate / count rows
+    E = int(vaid.numel())
+    sess = torch.repeat_interleave(torch.arange(sessions, device=dev), voff[1:] - voff[:-1], output_size=E)
+    key = sess * (1 << 22) + vaid.long()
+    src = {'U': torch.unique(key) % (1 << 22), 'CC': torch.unique(key[vtyp <= 1]) % (1 << 22)}
+    entries = sum(int(mats[kind][2][src[s_]].sum().item()) for kind, s_ in cd.CLICK_RECIPE)
+    lookup_bytes = 4 * entries + 5 * E + sessions * (100 * 8 + 4)
     for name, fn in (('lookup_click_recipe', lambda: cd.candidate_lookup(vaid, vtyp, voff, mats, cd.CLICK_RECIPE)),
                      ('recency', lambda: cd.recency_candidates(vaid, vtyp, voff))):
         fn()
@@ -157,8 +165,91 @@ def candidates_leg(data, dev, n_aids, train_sessions=3_000_000, sessions=1_800_0
         torch.cuda.synchronize(dev)
         ms = 1e3 * (time.time() - t0) / 3
         out[name] = {'ms': round(ms, 2), 'sessions_per_s': round(sessions / (ms * 1e-3), 1)}
+        if name == 'lookup_click_recipe':
+            out[name]['roofline'] = {**roofline_obj('k_cand<32, 10, 128> + k_cand<512, 12, 512> (host wall time of both launches)', ms, lookup_bytes),
+                                     'list_entries': entries,
+                                     'note': 'one workgroup per session, LDS hash + selection: latency bound, not an HBM stream'}
     out['config'] = f'{sessions} sessions, {int(vaid.numel())} events, top-15 matrices from {train_sessions} sessions'
     return out
+
+
+def next_rows_leg(data, dev, n_aids, cand_sessions=1_800_000):
+    """The rows SURVEY.md section 8 marks "next", device-resident inputs, each with a roofline object (algorithmic bytes =
+    inputs read once + outputs written once; the radix sort and the pair sorts move several times that by construction):
+    f2 event ingest (shuffled full-size frame, ms timestamps -> sorted SoA + CSR), a6 aid-pair builders, f4 interaction
+    features over a validation-sized [S, 100] candidate table."""
+    import ctypes as C
+    import torch
+    from otto_amd import _lib
+    from otto_amd.events import DeviceEvents
+    from otto_amd.matrix_factorization.data import build_aid_pairs_device
+    from otto_amd.ranker.interaction_feature_engineering import interaction_features
+    lib = _lib.lib()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    stream = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    S, E = data['sess_off'].numel() - 1, data['aid'].numel()
+
+    def timed(fn, reps=2):
+        best, out = 1e30, None
+        for _ in range(reps):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize(dev)
+            best = min(best, time.perf_counter() - t0)
+        return 1e3 * best, out
+    res = {}
+    sess = torch.repeat_interleave(torch.arange(S, device=dev, dtype=torch.int32), data['sess_off'][1:] - data['sess_off'][:-1], output_size=E)
+    perm = torch.randperm(E, device=dev)
+    f_sess, f_aid, f_type = sess[perm].contiguous(), data['aid'][perm].contiguous(), data['type'][perm].contiguous()
+    f_ts = (data['ts'][perm].to(torch.int64) * 1000 + 7).contiguous()
+    del perm, sess
+    ws_b = int(lib.otto_events_sort_workspace(E))
+    ws = torch.empty(ws_b, dtype=torch.uint8, device=dev)
+    o_aid, o_ts = torch.empty(E, dtype=torch.int32, device=dev), torch.empty(E, dtype=torch.int32, device=dev)
+    o_type, o_order = torch.empty(E, dtype=torch.uint8, device=dev), torch.empty(E, dtype=torch.int32, device=dev)
+    o_off, o_id = torch.empty(E + 1, dtype=torch.int64, device=dev), torch.empty(E, dtype=torch.int32, device=dev)
+    ns = C.c_int64()
+
+    def sort_events():
+        _lib.check(lib.otto_events_sort(p(f_sess), p(f_ts), p(f_aid), p(f_type), E, 1000, p(o_aid), p(o_ts), p(o_type), p(o_order), p(o_off),
+                                        p(o_id), C.byref(ns), p(ws), ws_b, stream()), 'otto_events_sort')
+    ms, _ = timed(sort_events, 3)
+    ok = ns.value == S and bool((o_ts == data['ts']).all())
+    res['f2_events_sort'] = {'ms': round(ms, 2), 'events_per_s': round(E / (ms * 1e-3), 1), 'sorted_correctly': ok,
+                             'roofline': roofline_obj('otto_events_sort: k_rs_hist + k_rs_scatter x digit passes + gather (host wall time)', ms,
+                                                      E * (17 + 13) + S * 12)}
+    del f_sess, f_aid, f_type, f_ts, ws, o_aid, o_ts, o_type, o_order, o_off, o_id
+    ev = DeviceEvents(data['aid'], data['ts'], data['type'], data['sess_off'], torch.arange(S, device=dev), None, n_aids)
+    for strat in ('diff', 'time'):
+        ms, out = timed(lambda: build_aid_pairs_device(ev, strat, hour_difference=1, target_aggregation='mean', sample_frac=0.15, seed=42))
+        rows = int(out[0].numel())
+        read = E * 8 + S * 8 if strat == 'diff' else int(0.15 * E) * 8 + S * 8
+        res[f'a6_pairs_{strat}'] = {'ms': round(ms, 1), 'labelled_pairs': rows,
+                                    'roofline': roofline_obj(f'otto_pairs_{strat} (emit + radix sort by pair + aggregate; host wall time incl. workspace allocation)',
+                                                             ms, read + rows * 24)}
+        del out
+    Sv = min(cand_sessions, S)
+    off = (data['sess_off'][S - Sv:] - data['sess_off'][S - Sv]).contiguous()
+    e0 = int(data['sess_off'][S - Sv])
+    v_aid, v_type = data['aid'][e0:].contiguous(), data['type'][e0:].contiguous()
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    cand = torch.randint(0, n_aids, (Sv, 100), device=dev, generator=g, dtype=torch.int32)
+    cand, _ = torch.sort(cand, dim=1)
+    dup = torch.zeros_like(cand, dtype=torch.bool)
+    dup[:, 1:] = cand[:, 1:] == cand[:, :-1]
+    cand[dup] = -1
+    cand, _ = torch.sort(cand, dim=1, descending=True)
+    cand[:, 0] = v_aid[torch.minimum(off[:-1] + 0, off[1:] - 1)]
+    cand = cand.contiguous()
+    scores = torch.rand((Sv, 100), device=dev, generator=g)
+    ms, _ = timed(lambda: interaction_features(v_aid, v_type, off, cand, scores, n_aids), 3)
+    rows = int((cand >= 0).sum())
+    res['f4_interaction_features'] = {'ms': round(ms, 2), 'rows': rows, 'rows_per_s': round(rows / (ms * 1e-3), 1),
+                                      'roofline': roofline_obj('k_inter_rows + k_inter_aids (host wall time)', ms,
+                                                               Sv * 100 * (4 + 4 + 10) + int(v_aid.numel()) * 5 + Sv * 40 + n_aids * 36)}
+    return res
 
 
 def dropin_leg(data, dev, n_aids, ts_min, ts_max, k, reps=2):
@@ -444,6 +535,11 @@ def main():
             result['candidates'] = candidates_leg(data, dev, n_aids)
         except Exception as e:                                   # a reported extra, never a reason to lose the bench line
             result['candidates'] = {'error': repr(e)}
+    if rank == 0 and world == 1 and not a.no_mf:
+        try:
+            result['next_rows'] = next_rows_leg(data, dev, n_aids)
+        except Exception as e:                                   # a reported extra, never a reason to lose the bench line
+            result['next_rows'] = {'error': repr(e)}
     if rank == 0 and world == 1 and a.cpu_sessions > 0:
         result['cpu_baseline'] = cpu_baseline(data, min(a.cpu_sessions, a.sessions), a.k)
     if rank == 0:

@@ -40,17 +40,21 @@ TOP15_CART_ORDER_PARTS = {'validation': 1, 'submission': 2}
 TOP_PARTS, TOP_CART_ORDER_PARTS = 6, 2                  # ranker/regular_candidate_generation.py:75-101
 
 
+COLUMNS = ['session', 'aid', 'ts', 'type']
+
+
 def load_events(mode):
-    import pandas as pd
+    """The event frames the reference reads (``src/ranker/aid_feature_engineering.py:21-36``) as a LIST -- validation: two
+    pyarrow tables straight from the parquet column chunks (no pandas frame); submission: the two pickled frames (pickle
+    can only produce pandas frames; their columns are handed over zero-copy). They are never concatenated on the host:
+    ``frame_to_events_device`` copies every column chunk into one page-locked staging buffer and sorts on the device."""
     if mode == 'validation':
-        df = pd.concat((pd.read_parquet(settings.DATA / 'splits' / 'train.parquet'),
-                        pd.read_parquet(settings.DATA / 'splits' / 'val.parquet')), axis=0, ignore_index=True)
-    elif mode == 'submission':
-        df = pd.concat((pd.read_pickle(settings.DATA / 'train.pkl'), pd.read_pickle(settings.DATA / 'test.pkl')),
-                       axis=0, ignore_index=True)
-    else:
-        raise ValueError('Invalid mode')
-    return df
+        import pyarrow.parquet as pq
+        return [pq.read_table(str(settings.DATA / 'splits' / f'{name}.parquet'), columns=COLUMNS) for name in ('train', 'val')]
+    if mode == 'submission':
+        import pandas as pd
+        return [pd.read_pickle(settings.DATA / f'{name}.pkl') for name in ('train', 'test')]
+    raise ValueError('Invalid mode')
 
 
 def split_parts(aid_x, n_parts, n_aids):

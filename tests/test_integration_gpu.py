@@ -427,6 +427,13 @@ def test_device_frame_to_events_equals_numpy_path(gpu_device, variant):
         fr['ts'] = pd.to_datetime(fr['ts'], unit='s')
     want, want_ids = frame_to_events(fr)
     src = pa.Table.from_pandas(fr, preserve_index=False) if variant == 'arrow-table' else fr
+    if variant == 'arrow-table':
+        # the builder's loader hands over a LIST of tables (train + val), their columns in several chunks: no host concat
+        cut = len(fr) // 3
+        src = [pa.concat_tables([src.slice(0, cut // 2), src.slice(cut // 2, cut - cut // 2)]), src.slice(cut)]
+        assert src[0].column('aid').num_chunks == 2
+    elif variant == 'ms-uint64-strings':
+        src = [fr.iloc[:len(fr) // 2], fr.iloc[len(fr) // 2:]]           # two pandas frames (train.pkl + test.pkl)
     got = frame_to_events_device(src, device=gpu_device)
     host = got.to_host()
     assert got.n_sessions == want.n_sessions == 6000 and got.n_aids == want.n_aids
