@@ -36,7 +36,15 @@ struct CandArgs {
     uint32_t* err;
     int lo_len, hi_len;            // this launch handles sessions with lo_len <= events <= hi_len
     int32_t* self_count;           // nullable: [n_events] Counter count of every event's aid; the session's aids then leave the selection
+#ifdef OTTO_PHASE_PROF
+    unsigned long long* prof;      // [8] shader-clock ticks of thread 0 per phase (diagnostic build)
+#endif
 };
+#ifdef OTTO_PHASE_PROF
+#define CD_PH(i) do { if (threadIdx.x == 0) { const unsigned long long _t = clock64(); ph[i] += _t - ph_t; ph_t = _t; } } while (0)
+#else
+#define CD_PH(i) do {} while (0)
+#endif
 
 __device__ __forceinline__ uint64_t cand_key(uint64_t count, uint32_t fp, uint32_t y) {
     return (count << 50) | ((uint64_t)(0xFFFFFFu - fp) << 26) | (uint64_t)y;
@@ -70,11 +78,15 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
     const int tid = threadIdx.x, wid = tid >> 6;
     const unsigned lane = lane_id();
     const int K = a.p.k, NC = a.p.n_common;
+#ifdef OTTO_PHASE_PROF
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = clock64();
+#endif
 
     for (int64_t s = blockIdx.x; s < a.n_sess; s += gridDim.x) {
         const int64_t lo = a.sess_off[s], hi = a.sess_off[s + 1];
         const int n = (int)(hi - lo);
         if (n < a.lo_len || n > a.hi_len) continue;        // the other variant's session
+        CD_PH(0);
         if (n > CD_MAXL) {
             if (tid == 0) atomicAdd(a.err, 1u);
             continue;
@@ -121,6 +133,7 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
         auto src_aid = [&](int src, uint32_t j) -> uint32_t {
             return s_aid[src == OTTO_CAND_SRC_LAST ? (uint32_t)(n - 1) : (uint32_t)s_src[src == OTTO_CAND_SRC_C ? 3 : src][j]];
         };
+        CD_PH(1);
         // ---- B ----------------------------------------------------------------------------------------
         uint32_t tstart[OTTO_CAND_MAX_TERMS + 1];
         tstart[0] = 0;
@@ -149,6 +162,7 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
             running += tot;
         }
         const uint32_t TOT = running;
+        CD_PH(2);
         // table size follows the concatenation: most sessions are short, and clearing / scanning 4096 slots for a few
         // hundred entries would dominate them
         const int lt0 = TOT <= 192u ? 8 : (TOT <= 768u ? 10 : CD_LOG2T);
@@ -190,6 +204,7 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
             if (tid == 0) { s_sp = sp - 1; s_ovf = 0; s_nfresh = 0; }
             for (int i = tid; i < Teff; i += CD_THREADS) { s_tab[i] = CD_EMPTY; s_fp[i] = 0xFFFFFFFFu; }
             __syncthreads();
+            CD_PH(3);
             const int hw = tid >> 5, l = tid & 31;
             // One half-wave per list, GU lists in flight per half-wave: the list rows come from global memory (L2 at best) and a
             // half-wave that waits for one row at a time spends the gather in load latency (a long session concatenates several
@@ -250,6 +265,7 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                 }
             }
             __syncthreads();
+            CD_PH(4);
             if (s_ovf) {                                      // split this partition: one more hash bit, two children
                 if (tid == 0) {
                     if (lgR + lt >= 32 || sp + 1 > (uint32_t)CD_STACK) atomicAdd(a.err, 1u << 16);      // cannot happen below 2^20 equal hash prefixes
@@ -376,6 +392,7 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
             }
             have_sel = true;
             __syncthreads();
+            CD_PH(5);
         }
         __syncthreads();
         // ---- drop the session's own aids, compact, write ---------------------------------------------------
@@ -406,7 +423,12 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
         for (int i = (int)total + tid; i < NC; i += CD_THREADS) { a.cand[s * NC + i] = -1; a.count[s * NC + i] = 0; }
         if (tid == 0) a.n_out[s] = (int32_t)total;
         __syncthreads();
+        CD_PH(6);
     }
+#ifdef OTTO_PHASE_PROF
+    if (threadIdx.x == 0 && a.prof)
+        for (int i = 0; i < 8; ++i) atomicAdd(&a.prof[i], ph[i]);
+#endif
 }
 
 // final predictions: unique session aids (most recent first) + candidates + global most frequent aids
@@ -780,13 +802,44 @@ static int cand_lookup(const otto_cand_params* p, const uint32_t* d_aid, const u
     a.p = *p;
     a.aid = d_aid; a.type = d_type; a.sess_off = d_sess_off; a.n_sess = n_sess;
     a.cand = d_cand; a.count = d_count; a.n_out = d_n; a.err = d_err; a.self_count = d_self;
+#ifdef OTTO_PHASE_PROF
+    static unsigned long long* d_prof = nullptr;
+    static hipEvent_t pe[3];
+    if (!d_prof) { OTTO_HIP(hipMalloc(&d_prof, 128)); for (auto& e : pe) OTTO_HIP(hipEventCreate(&e)); }
+    OTTO_HIP(hipMemsetAsync(d_prof, 0, 128, s));
+    a.prof = d_prof;
+    (void)hipEventRecord(pe[0], s);
+#endif
     // short sessions first (most of them), then the long ones; each variant skips the other's sessions
     a.lo_len = 0; a.hi_len = CD_SMALL_MAXL;
     const int grid_s = (int)(n_sess < 256 * 10 ? n_sess : 256 * 10);
     k_cand<CD_SMALL_MAXL, 10, 128><<<grid_s, 128, 0, s>>>(a);
+#ifdef OTTO_PHASE_PROF
+    a.prof = d_prof + 8;
+    (void)hipEventRecord(pe[1], s);
+#endif
     a.lo_len = CD_SMALL_MAXL + 1; a.hi_len = 0x7FFFFFFF;
     const int grid = (int)(n_sess < 256 * 2 ? n_sess : 256 * 2);
     k_cand<OTTO_CAND_MAX_SESSION, 12, 512><<<grid, 512, 0, s>>>(a);
+#ifdef OTTO_PHASE_PROF
+    {
+        (void)hipEventRecord(pe[2], s);
+        (void)hipStreamSynchronize(s);
+        unsigned long long h[16];
+        (void)hipMemcpy(h, d_prof, 128, hipMemcpyDeviceToHost);
+        float ms0 = 0.f, ms1 = 0.f;
+        (void)hipEventElapsedTime(&ms0, pe[0], pe[1]);
+        (void)hipEventElapsedTime(&ms1, pe[1], pe[2]);
+        const char* names[7] = {"skip", "A flags+ranks", "B lengths+scan", "clear", "gather+insert", "selection", "filter+write"};
+        for (int v = 0; v < 2; ++v) {
+            unsigned long long tot = 0;
+            for (int i = 0; i < 7; ++i) tot += h[v * 8 + i];
+            fprintf(stderr, "[phase-prof] k_cand %s  %.2f ms:", v == 0 ? "short sessions" : "long sessions", v == 0 ? ms0 : ms1);
+            for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.1f%%", names[i], tot ? 100.0 * h[v * 8 + i] / tot : 0.0);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     hipError_t le = hipGetLastError();
     uint32_t err = 0;
     hipError_t ce = hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s);

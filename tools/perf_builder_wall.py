@@ -41,10 +41,7 @@ for rep in range(2):
     out = os.path.join(tmp, 'covisitation', 'validation')
     os.makedirs(out, exist_ok=True)
     import pathlib
-    for kind in builder.REFERENCE_KINDS:
-        co = kind == 'cart_order'
-        builder.write_parts(pathlib.Path(out), 'top_15', kind, res[15][kind], builder.TOP15_CART_ORDER_PARTS['validation'] if co else builder.TOP15_PARTS['validation'], ev.n_aids)
-        builder.write_parts(pathlib.Path(out), 'top', kind, res[20][kind], builder.TOP_CART_ORDER_PARTS if co else builder.TOP_PARTS, ev.n_aids)
+    builder.write_jobs(builder.all_part_jobs(pathlib.Path(out), 'validation', res, ev.n_aids))
     t4 = time.time()
     print(f'rep {rep}: parquet decode (pyarrow, {os.cpu_count()} host threads) {t1-t0:.2f} s | columns -> pinned staging -> device + sort {t2-t1:.2f} s | '
           f'7-kind build incl. top-k rows to host {t3-t2:.2f} s | write 2 x 7 part sets {t4-t3:.2f} s | total {t4-t0:.2f} s', flush=True)
