@@ -103,6 +103,7 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
             const uint32_t ai = s_aid[i];
             const uint32_t ti = s_ty[i];
             bool last = true, fcc = ti <= 1, fco = ti >= 1, fc = ti == 0;
+#pragma unroll 4
             for (int j = 0; j < n; ++j) {
                 if (s_aid[j] != ai) continue;
                 if (j > i) last = false;
@@ -113,20 +114,35 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
             s_flag[i] = (uint8_t)((last ? 1 : 0) | (fcc ? 2 : 0) | (fco ? 4 : 0) | (fc ? 8 : 0));
         }
         __syncthreads();
-        for (int i = tid; i < n; i += CD_THREADS) {
-            const uint32_t ai = s_aid[i], fl = s_flag[i];
-            uint32_t ru = 0, rcc = 0, rco = 0, rc = 0;
-            for (int j = 0; j < n; ++j) {
-                const uint32_t fj = s_flag[j], aj = s_aid[j];
-                ru += (j > i) & (fj & 1u);
-                rcc += ((fj >> 1) & 1u) & (aj < ai);
-                rco += ((fj >> 2) & 1u) & (aj < ai);
-                rc += ((fj >> 3) & 1u) & (aj < ai);
+        for (int i0 = 0; i0 < n; i0 += CD_THREADS) {            // (uniform trip count: the list sizes come from wave ballots)
+            const int i = i0 + tid;
+            uint32_t fl = 0;
+            if (i < n) {
+                const uint32_t ai = s_aid[i];
+                fl = s_flag[i];
+                uint32_t ru = 0, rcc = 0, rco = 0, rc = 0;
+#pragma unroll 4
+                for (int j = 0; j < n; ++j) {
+                    const uint32_t fj = s_flag[j], aj = s_aid[j];
+                    ru += (j > i) & (fj & 1u);
+                    rcc += ((fj >> 1) & 1u) & (aj < ai);
+                    rco += ((fj >> 2) & 1u) & (aj < ai);
+                    rc += ((fj >> 3) & 1u) & (aj < ai);
+                }
+                if (fl & 1u) s_src[0][ru] = (uint16_t)i;
+                if (fl & 2u) s_src[1][rcc] = (uint16_t)i;
+                if (fl & 4u) s_src[2][rco] = (uint16_t)i;
+                if (fl & 8u) s_src[3][rc] = (uint16_t)i;
             }
-            if (fl & 1u) { s_src[0][ru] = (uint16_t)i; atomicAdd(&s_nsrc[0], 1u); }
-            if (fl & 2u) { s_src[1][rcc] = (uint16_t)i; atomicAdd(&s_nsrc[1], 1u); }
-            if (fl & 4u) { s_src[2][rco] = (uint16_t)i; atomicAdd(&s_nsrc[2], 1u); }
-            if (fl & 8u) { s_src[3][rc] = (uint16_t)i; atomicAdd(&s_nsrc[4], 1u); }
+            // list sizes: one LDS atomic per wave and list instead of one per event on the same address
+            const uint32_t c0 = (uint32_t)__popcll(__ballot(fl & 1u)), c1 = (uint32_t)__popcll(__ballot(fl & 2u));
+            const uint32_t c2 = (uint32_t)__popcll(__ballot(fl & 4u)), c3 = (uint32_t)__popcll(__ballot(fl & 8u));
+            if (lane == 0) {
+                if (c0) atomicAdd(&s_nsrc[0], c0);
+                if (c1) atomicAdd(&s_nsrc[1], c1);
+                if (c2) atomicAdd(&s_nsrc[2], c2);
+                if (c3) atomicAdd(&s_nsrc[4], c3);
+            }
         }
         __syncthreads();
         // aid of entry j of source list `src` (OTTO_CAND_SRC_*)
@@ -238,9 +254,11 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                             }
                         }
                     }
+                    uint32_t nfr = 0;                             // keys this wave entered with this batch
 #pragma unroll
                     for (int u = 0; u < GU; ++u) {
-                        if (!ok[u]) continue;
+                        bool fr = false;
+                        if (ok[u]) {
                         const uint32_t y = yv[u];
                         const uint32_t h = y * 0x9E3779B1u;
                         if (lgR == 0 || ((h >> (32 - lt - lgR)) & (R - 1u)) == part) {
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                                 const bool fresh = old == CD_EMPTY;
                                 if (fresh || (uint32_t)(old >> 32) == y) {
                                     if (!fresh) atomicAdd(&s_tab[slot], 1ull);
-                                    else if (TOT > (uint32_t)CD_CAP && atomicAdd(&s_nfresh, 1u) >= (uint32_t)CD_CAP) s_ovf = 1;   // too full to probe cheaply
+                                    fr = fresh;
                                     atomicMin(&s_fp[slot], pv[u]);
                                     placed = true;
                                     break;
@@ -261,7 +279,12 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                             }
                             if (!placed) s_ovf = 1;
                         }
+                        }
+                        nfr += (uint32_t)__popcll(__ballot(fr));
                     }
+                    // distinct aids of the partition so far: ONE LDS atomic per wave and batch (a counter bumped by every new key
+                    // is a 64-way same-address conflict per wave-instruction: it was the long sessions' largest single cost)
+                    if (TOT > (uint32_t)CD_CAP && nfr != 0 && (tid & 63) == 0 && atomicAdd(&s_nfresh, nfr) + nfr > (uint32_t)CD_CAP) s_ovf = 1;
                 }
             }
             __syncthreads();
