@@ -263,6 +263,9 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                         const uint32_t h = y * 0x9E3779B1u;
                         if (lgR == 0 || ((h >> (32 - lt - lgR)) & (R - 1u)) == part) {
                             uint32_t slot = h >> (32 - lt);
+                            // double hashing (odd step from a second hash: every slot is visited): linear probing builds
+                            // clusters at the 3/4 load a partition may reach, and a wave waits for its longest chain
+                            const uint32_t step = ((y * 0x85EBCA6Bu) >> (32 - lt)) | 1u;
                             bool placed = false;
                             for (int probe = 0; probe < Teff; ++probe) {
                                 // CAS first: a new aid goes in together with its first count
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                                     placed = true;
                                     break;
                                 }
-                                slot = (slot + 1) & (uint32_t)(Teff - 1);
+                                slot = (slot + step) & (uint32_t)(Teff - 1);
                             }
                             if (!placed) s_ovf = 1;
                         }
@@ -308,11 +311,12 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                     const uint32_t h = x * 0x9E3779B1u;
                     if (lgR != 0 && ((h >> (32 - lt - lgR)) & (R - 1u)) != part) return -1;
                     uint32_t slot = h >> (32 - lt);
+                    const uint32_t step = ((x * 0x85EBCA6Bu) >> (32 - lt)) | 1u;
                     for (int probe = 0; probe < Teff; ++probe) {
                         const unsigned long long v = s_tab[slot];
                         if (v == CD_EMPTY) return -1;
                         if ((uint32_t)(v >> 32) == x) return (int)slot;
-                        slot = (slot + 1) & (uint32_t)(Teff - 1);
+                        slot = (slot + step) & (uint32_t)(Teff - 1);
                     }
                     return -1;
                 };
