@@ -3416,7 +3416,7 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
         else OTTO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_expand_fused<false, false>, 256, 0));
         const int64_t resident = (int64_t)(per_cu > 0 ? per_cu : 4) * (n_cu > 0 ? n_cu : 256);   // one round of resident workgroups
         const int grid = (int)(blocks < resident ? blocks : resident);
-        kname(c, OTTO_COVIS_T_EXPAND, lists ? "k_expand_lists<%s>" : "k_expand_fused<%s>", p.want_time ? "true" : "false");
+        kname(c, OTTO_COVIS_T_EXPAND, lists ? "k_expand_lists<%s, %s>" : "k_expand_fused<%s, %s>", p.want_time ? "true" : "false", a.debug ? "true" : "false");
         if (lists) {
             if (a.debug) {
                 if (p.want_time) k_expand_lists<true, true><<<grid, 256, 0, s>>>(a, n_sess);
