@@ -153,6 +153,14 @@ int otto_covis_export_plan(otto_covis_ctx* ctx, int n_owners, const uint32_t* h_
                            int64_t* h_n_recs, void* stream);
 int otto_covis_export_fill(otto_covis_ctx* ctx, int n_owners, const uint32_t* h_bounds, uint32_t* d_hdr, uint32_t* d_rec,
                            uint32_t* d_tw, void* stream);
+/* The same two passes over the run slots [slot_lo, slot_hi) only (run slots: 0 .. OTTO_COVIS_STAT_TAIL_EVENTS): the exchange
+ * is cut into a few slot ranges so that the fill of range c + 1 runs while range c is on the links. The planned counts
+ * travel through the caller (plan_range's outputs are fill_range's inputs), not through the context. */
+int otto_covis_export_plan_range(otto_covis_ctx* ctx, int n_owners, const uint32_t* h_bounds, int64_t slot_lo, int64_t slot_hi,
+                                 int64_t* h_n_runs, int64_t* h_n_recs, void* stream);
+int otto_covis_export_fill_range(otto_covis_ctx* ctx, int n_owners, const uint32_t* h_bounds, int64_t slot_lo, int64_t slot_hi,
+                                 const int64_t* h_n_runs, const int64_t* h_n_recs, uint32_t* d_hdr, uint32_t* d_rec, uint32_t* d_tw,
+                                 void* stream);
 
 /* Test hook: copy the raw K1 output to HOST buffers (any pointer may be NULL).
  * h_rec/h_tw: [PAIR_SLOTS] uint32, h_run_x: [TAIL_EVENTS] uint32, h_run_desc: [TAIL_EVENTS] uint64

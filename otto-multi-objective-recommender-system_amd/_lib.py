@@ -103,6 +103,8 @@ SIGNATURES = {
     'otto_covis_import_reserve': (_i32, [_vp, _i64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp]),
     'otto_covis_export_plan': (_i32, [_vp, _i32, _vp, _p_i64, _p_i64, _vp]),
     'otto_covis_export_fill': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'otto_covis_export_plan_range': (_i32, [_vp, _i32, _vp, _i64, _i64, _p_i64, _p_i64, _vp]),
+    'otto_covis_export_fill_range': (_i32, [_vp, _i32, _vp, _i64, _i64, _p_i64, _p_i64, _vp, _vp, _vp, _vp]),
     'otto_covis_copy_records': (_i32, [_vp, _vp, _vp, _vp, _vp]),
     'otto_covis_timings': (_i32, [_vp, C.POINTER(C.c_float)]),
     'otto_covis_kernel_names': (_i32, [_vp, _i32, C.c_char_p, _i32]),

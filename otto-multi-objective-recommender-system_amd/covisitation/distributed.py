@@ -72,6 +72,59 @@ def exchange_runs(export_fn, import_fn, bounds, group=None, want_time=False, sta
     return int(sc[:, 0].sum()), int(sc[:, 1].sum()), int(rc[:, 0].sum()), int(rc[:, 1].sum())
 
 
+def exchange_runs_chunked(engine, owner, bounds, group=None, want_time=False, n_chunks=4):
+    """The same exchange cut into ``n_chunks`` ranges of run slots, so that the export of range c + 1 (a pass over its run
+    descriptors + the record copies, ~6 ms for a full-size shard) runs on the compute stream while range c is on the links:
+    the collectives are issued asynchronously right behind the fill they depend on (torch.distributed orders a collective
+    after the work already queued on the current stream, nothing more). All counts are planned and exchanged first (one
+    small all-to-all), the records of every range are received straight into the owner engine's arrays
+    (``import_reserve``), range after range, and registered with ONE ``import_runs`` at the end. Device tensors only (RCCL
+    or a world of one); the staged rehearsal path stays ``exchange_runs``.
+    Returns (runs_sent, recs_sent, runs_received, recs_received)."""
+    import torch
+    import torch.distributed as dist
+    W = dist.get_world_size(group)
+    slots = engine.run_slots()
+    K = max(1, min(int(n_chunks), slots if slots else 1))
+    cuts = [slots * c // K for c in range(K + 1)]
+    plans = [engine.export_plan_range(bounds, cuts[c], cuts[c + 1]) for c in range(K)]
+    dev = engine.device
+    # counts: [W dest][K][2] -> every source's [K][2] for me
+    send_counts = torch.tensor([[[plans[c][0][o], plans[c][1][o]] for c in range(K)] for o in range(W)], dtype=torch.int64, device=dev)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts.view(-1), send_counts.view(-1), group=group)
+    rc = recv_counts.cpu().numpy()                          # [W src][K][2]
+    tot_runs_in, tot_recs_in = int(rc[:, :, 0].sum()), int(rc[:, :, 1].sum())
+    rec_in, tw_in = owner.import_reserve(tot_recs_in) if tot_recs_in else (None, None)
+    if rec_in is None:
+        rec_in = torch.empty(0, dtype=torch.int32, device=dev)
+    hdr_in = torch.empty((tot_runs_in, 2), dtype=torch.int32, device=dev)
+    handles, keep = [], []
+    r0 = c0 = 0
+    for c in range(K):
+        runs, recs = plans[c]
+        hdr_s = torch.empty((sum(runs), 2), dtype=torch.int32, device=dev)
+        rec_s = torch.empty(sum(recs), dtype=torch.int32, device=dev)
+        tw_s = torch.empty(sum(recs), dtype=torch.int32, device=dev) if want_time else None
+        engine.export_fill_range(bounds, cuts[c], cuts[c + 1], runs, recs, hdr_s, rec_s, tw_s)
+        nr, nc = int(rc[:, c, 0].sum()), int(rc[:, c, 1].sum())
+        jobs = [(hdr_in[r0:r0 + nr].view(-1), hdr_s.view(-1), [int(v) * 2 for v in rc[:, c, 0]], [int(v) * 2 for v in runs]),
+                (rec_in[c0:c0 + nc], rec_s, [int(v) for v in rc[:, c, 1]], [int(v) for v in recs])]
+        if want_time:
+            jobs.append((tw_in[c0:c0 + nc], tw_s, [int(v) for v in rc[:, c, 1]], [int(v) for v in recs]))
+        for out, inp, osz, isz in jobs:
+            handles.append(dist.all_to_all_single(out, inp, osz, isz, group=group, async_op=True))
+        keep.append((hdr_s, rec_s, tw_s))                   # send buffers stay alive until the collectives are done
+        r0 += nr
+        c0 += nc
+    for h in handles:
+        h.wait()
+    if tot_runs_in:
+        owner.import_runs(hdr_in, rec_in[:tot_recs_in], tw_in[:tot_recs_in] if want_time else None)
+    sent = (sum(sum(p_[0]) for p_ in plans), sum(sum(p_[1]) for p_ in plans))
+    return sent[0], sent[1], tot_runs_in, tot_recs_in
+
+
 def global_ts_range(ts, group=None):
     """t0 / t1 of the time weight must be global over all ranks (SPEC-COVIS 6)."""
     import torch
@@ -87,11 +140,13 @@ class ShardedCovisBuilder:
     """Session-chunk sharded build on ``world`` GPUs; rank r owns aid_x in
     ``[bounds[r], bounds[r+1])`` and returns top-k rows for that range only."""
 
-    def __init__(self, n_aids, kinds, ts_min, ts_max, device, group=None, window=30, max_gap=86400, stage_device=None):
+    def __init__(self, n_aids, kinds, ts_min, ts_max, device, group=None, window=30, max_gap=86400, stage_device=None,
+                 exchange_chunks=4):
         import torch.distributed as dist
         from .engine import CovisBuilder
         self.group = group
         self.stage_device = stage_device
+        self.exchange_chunks = exchange_chunks    # device path: slot ranges in flight (export of c + 1 under the send of c); 0 = one piece
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.bounds = owner_bounds(n_aids, self.world)
@@ -107,6 +162,10 @@ class ShardedCovisBuilder:
         self.local.feed(aid, ts, typ, sess_off)
 
     def finalize(self, k=20, out=None):
+        if self.stage_device is None and self.exchange_chunks and self.exchange_chunks > 1:
+            self.last_exchange = exchange_runs_chunked(self.local, self.owner, self.bounds, self.group, self.local.want_time,
+                                                       self.exchange_chunks)
+            return self.owner.finalize(k=k, out=out)
         self.last_exchange = exchange_runs(self.local.export_runs, self.owner.import_runs, self.bounds, self.group,
                                            self.local.want_time, self.stage_device, export_all_fn=self.local.export_all,
                                            reserve_fn=self.owner.import_reserve)

@@ -175,6 +175,29 @@ class CovisBuilder:
                        'otto_covis_export_fill')
         return hdr, rec, tw, runs, recs
 
+    def export_plan_range(self, bounds, slot_lo, slot_hi):
+        """(runs_per_owner, recs_per_owner) of the run slots [slot_lo, slot_hi) (chunked exchange; synchronises the stream)."""
+        W = len(bounds) - 1
+        hb = (C.c_uint32 * (W + 1))(*[int(b) for b in bounds])
+        nr, nc = (C.c_int64 * W)(), (C.c_int64 * W)()
+        with self.torch.cuda.device(self.device):
+            _lib.check(self._lib.otto_covis_export_plan_range(self._ctx, W, hb, C.c_int64(int(slot_lo)), C.c_int64(int(slot_hi)), nr, nc,
+                                                              self._stream()), 'otto_covis_export_plan_range')
+        return [int(v) for v in nr], [int(v) for v in nc]
+
+    def export_fill_range(self, bounds, slot_lo, slot_hi, runs, recs, hdr, rec, tw=None):
+        """Fills the owner-major send buffers of one slot range (``hdr`` int32 [sum(runs), 2], ``rec`` int32 [sum(recs)],
+        ``tw`` like rec or None) on the current stream; no synchronisation."""
+        W = len(bounds) - 1
+        hb = (C.c_uint32 * (W + 1))(*[int(b) for b in bounds])
+        nr, nc = (C.c_int64 * W)(*runs), (C.c_int64 * W)(*recs)
+        with self.torch.cuda.device(self.device):
+            _lib.check(self._lib.otto_covis_export_fill_range(self._ctx, W, hb, C.c_int64(int(slot_lo)), C.c_int64(int(slot_hi)), nr, nc,
+                                                              _ptr(hdr), _ptr(rec), _ptr(tw), self._stream()), 'otto_covis_export_fill_range')
+
+    def run_slots(self):
+        return self.stats()['tail_events']
+
     def import_reserve(self, n_recs):
         """Zero-copy receive buffers: int32 tensors (rec, tw|None) that alias the end of the context's own record arrays.
         Fill them (e.g. as the output of the all-to-all-v) and hand them to ``import_runs``: no device copy is made."""

@@ -3071,7 +3071,8 @@ constexpr int MAX_OWNERS = 64;
 struct OwnerArgs {
     const uint32_t* run_x;
     const uint64_t* run_desc;
-    int64_t n_slots;
+    int64_t slot0;                       // first run slot of the range this call covers (chunked export)
+    int64_t n_slots;                     // run slots of the range
     int n_owners;
     uint32_t bounds[MAX_OWNERS + 1];     // owner o holds aid_x in [bounds[o], bounds[o+1])
     uint64_t run_base[MAX_OWNERS];       // fill: first run / record of owner o inside the output buffers
@@ -3100,9 +3101,9 @@ __global__ __launch_bounds__(256) void k_export_plan(OwnerArgs a) {
     if (threadIdx.x < MAX_OWNERS) s_tot[threadIdx.x] = 0;
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_slots; i += (int64_t)gridDim.x * 256) {
-        const uint64_t d = a.run_desc[i];
+        const uint64_t d = a.run_desc[a.slot0 + i];
         const uint32_t len = desc_pairs(d);
-        if (len) atomicAdd(&s_tot[owner_of(a, a.run_x[i])], (1ull << EXP_REC_BITS) | len);
+        if (len) atomicAdd(&s_tot[owner_of(a, a.run_x[a.slot0 + i])], (1ull << EXP_REC_BITS) | len);
     }
     __syncthreads();
     if ((int)threadIdx.x < a.n_owners && s_tot[threadIdx.x]) atomicAdd(&a.totals[threadIdx.x], s_tot[threadIdx.x]);
@@ -3128,9 +3129,9 @@ __global__ __launch_bounds__(256) void k_export_fill(OwnerArgs a) {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int64_t i = ch * EXP_CHUNK + (int64_t)u * 256 + threadIdx.x;
-            d[u] = i < a.n_slots ? a.run_desc[i] : 0ull;
+            d[u] = i < a.n_slots ? a.run_desc[a.slot0 + i] : 0ull;
             x[u] = 0; o[u] = 0; my_run[u] = my_rec[u] = 0;
-            if (desc_len(d[u])) x[u] = a.run_x[i];
+            if (desc_len(d[u])) x[u] = a.run_x[a.slot0 + i];
         }
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -4110,14 +4111,18 @@ extern "C" int otto_covis_export_runs(otto_covis_ctx* c, uint32_t x_lo, uint32_t
     return 0;
 }
 
-static int owner_args(otto_covis_ctx* c, int n_owners, const uint32_t* h_bounds, OwnerArgs& a) {
+static int owner_args(otto_covis_ctx* c, int n_owners, const uint32_t* h_bounds, OwnerArgs& a, int64_t slot_lo = 0, int64_t slot_hi = -1) {
     OTTO_REQUIRE(c && h_bounds, "null argument");
     OTTO_REQUIRE(n_owners >= 1 && n_owners <= MAX_OWNERS, "n_owners must be in [1, %d]", MAX_OWNERS);
     for (int o = 0; o < n_owners; ++o) OTTO_REQUIRE(h_bounds[o] <= h_bounds[o + 1], "owner bounds must be non-decreasing");
+    if (slot_hi < 0) slot_hi = (int64_t)c->run_used;
+    OTTO_REQUIRE(slot_lo >= 0 && slot_lo <= slot_hi && slot_hi <= (int64_t)c->run_used, "run slot range [%lld, %lld) outside [0, %llu]",
+                 (long long)slot_lo, (long long)slot_hi, (unsigned long long)c->run_used);
     memset(&a, 0, sizeof a);
     a.run_x = c->run_x.as<uint32_t>();
     a.run_desc = c->run_desc.as<uint64_t>();
-    a.n_slots = (int64_t)c->run_used;
+    a.slot0 = slot_lo;
+    a.n_slots = slot_hi - slot_lo;
     a.n_owners = n_owners;
     for (int o = 0; o <= n_owners; ++o) a.bounds[o] = h_bounds[o];
     a.bounds[0] = 0;
@@ -4177,6 +4182,65 @@ extern "C" int otto_covis_export_fill(otto_covis_ctx* c, int n_owners, const uin
     const int64_t nb = (a.n_slots + EXP_CHUNK - 1) / EXP_CHUNK;
     k_export_fill<<<(unsigned)(nb < 256 * 8 ? nb : 256 * 8), 256, 0, s>>>(a);
     OTTO_HIP(hipGetLastError());
+    return 0;
+}
+
+// The same two passes over a RANGE of run slots (chunked exchange: the fill of chunk c + 1 runs while chunk c is on the
+// links). The counts travel through the caller (plan_range -> fill_range), not through the context.
+extern "C" int otto_covis_export_plan_range(otto_covis_ctx* c, int n_owners, const uint32_t* h_bounds, int64_t slot_lo, int64_t slot_hi,
+                                            int64_t* h_n_runs, int64_t* h_n_recs, void* stream) {
+    OTTO_REQUIRE(h_n_runs && h_n_recs, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    OwnerArgs a;
+    OTTO_TRY(owner_args(c, n_owners, h_bounds, a, slot_lo, slot_hi));
+    OTTO_REQUIRE(c->run_used < (1ull << (64 - EXP_REC_BITS)) && c->rec_used < (1ull << EXP_REC_BITS), "too many runs for the packed export cursor");
+    OTTO_TRY(c->exp_totals.ensure(2 * MAX_OWNERS * 8, 0, s));
+    OTTO_HIP(hipMemsetAsync(c->exp_totals.p, 0, 2 * MAX_OWNERS * 8, s));
+    a.totals = c->exp_totals.as<unsigned long long>();
+    if (a.n_slots) {
+        const int64_t nb = (a.n_slots + 255) / 256;
+        k_export_plan<<<(unsigned)(nb < 256 * 8 ? nb : 256 * 8), 256, 0, s>>>(a);
+        OTTO_HIP(hipGetLastError());
+    }
+    unsigned long long t[MAX_OWNERS];
+    OTTO_HIP(hipMemcpyAsync(t, c->exp_totals.p, sizeof t, hipMemcpyDeviceToHost, s));
+    OTTO_HIP(hipStreamSynchronize(s));
+    for (int o = 0; o < n_owners; ++o) {
+        h_n_runs[o] = (int64_t)(t[o] >> EXP_REC_BITS);
+        h_n_recs[o] = (int64_t)(t[o] & ((1ull << EXP_REC_BITS) - 1ull));
+    }
+    c->exp_planned = 0;
+    return 0;
+}
+
+extern "C" int otto_covis_export_fill_range(otto_covis_ctx* c, int n_owners, const uint32_t* h_bounds, int64_t slot_lo, int64_t slot_hi,
+                                            const int64_t* h_n_runs, const int64_t* h_n_recs, uint32_t* d_hdr, uint32_t* d_rec,
+                                            uint32_t* d_tw, void* stream) {
+    OTTO_REQUIRE(h_n_runs && h_n_recs, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    OwnerArgs a;
+    OTTO_TRY(owner_args(c, n_owners, h_bounds, a, slot_lo, slot_hi));
+    OTTO_REQUIRE(!d_tw || c->p.want_time, "no time channel to export");
+    uint64_t rb = 0, cb = 0;
+    for (int o = 0; o < n_owners; ++o) {
+        OTTO_REQUIRE(h_n_runs[o] >= 0 && h_n_recs[o] >= 0, "negative planned count");
+        a.run_base[o] = rb;
+        a.rec_base[o] = cb;
+        rb += (uint64_t)h_n_runs[o];
+        cb += (uint64_t)h_n_recs[o];
+    }
+    if (rb == 0) return 0;
+    OTTO_REQUIRE(d_hdr && d_rec, "null export buffers");
+    OTTO_TRY(c->exp_totals.ensure(2 * MAX_OWNERS * 8, 0, s));
+    OTTO_HIP(hipMemsetAsync(c->exp_totals.p, 0, 2 * MAX_OWNERS * 8, s));
+    a.totals = c->exp_totals.as<unsigned long long>();
+    a.rec = c->rec.as<uint32_t>();
+    a.tw = c->tw.as<uint32_t>();
+    a.o_hdr = d_hdr; a.o_rec = d_rec; a.o_tw = d_tw;
+    const int64_t nb = (a.n_slots + EXP_CHUNK - 1) / EXP_CHUNK;
+    k_export_fill<<<(unsigned)(nb < 256 * 8 ? nb : 256 * 8), 256, 0, s>>>(a);
+    OTTO_HIP(hipGetLastError());
+    c->exp_planned = 0;
     return 0;
 }
 

@@ -326,6 +326,52 @@ def test_multi_gpu_exchange_roundtrip(gpu_device):
     _assert_rows_equal(merged, want, kinds)
 
 
+@pytest.mark.parametrize('kinds', [NOFILT, cs.ALL_KINDS], ids=['lists', 'class-kernels'])
+def test_chunked_export_by_run_slot_ranges(gpu_device, kinds):
+    """The pipelined exchange cuts the export into ranges of run slots (plan_range / fill_range: the fill of range c + 1
+    runs while range c is on the links): 5 ranges x 3 owners by hand -- planned counts, filled buffers imported range
+    after range into owner contexts -- equal the single-context build; the planned counts of the ranges add up to the
+    one-piece plan. With the component lists a run reads a shared list: the export materialises private rows (the run's
+    own entry dropped, one time extra per record)."""
+    import torch
+    from otto_amd.covisitation.engine import CovisBuilder, topk_to_rows
+    ev = generate_sessions(2500, n_aids=500, seed=43)
+    b, want = _build(ev, gpu_device, kinds=kinds)
+    ts_min, ts_max = int(ev.ts.min()), int(ev.ts.max())
+    bounds = [0, 150, 151, ev.n_aids]                                   # a one-aid owner in the middle
+    slots = b.run_slots()
+    cuts = [slots * c // 5 for c in range(6)]
+    whole = b.export_all(bounds)
+    owners = [CovisBuilder(ev.n_aids, kinds=kinds, ts_min=ts_min, ts_max=ts_max, device=gpu_device) for _ in range(3)]
+    tot_runs, tot_recs = [0, 0, 0], [0, 0, 0]
+    for c in range(5):
+        runs, recs = b.export_plan_range(bounds, cuts[c], cuts[c + 1])
+        hdr = torch.empty((sum(runs), 2), dtype=torch.int32, device=gpu_device)
+        rec = torch.empty(sum(recs), dtype=torch.int32, device=gpu_device)
+        tw = torch.empty(sum(recs), dtype=torch.int32, device=gpu_device) if b.want_time else None
+        b.export_fill_range(bounds, cuts[c], cuts[c + 1], runs, recs, hdr, rec, tw)
+        r0 = c0 = 0
+        for o in range(3):
+            if runs[o]:
+                h_o = hdr[r0:r0 + runs[o]].contiguous()
+                assert ((h_o[:, 0] >= bounds[o]) & (h_o[:, 0] < bounds[o + 1])).all() and int(h_o[:, 1].sum()) == recs[o]
+                owners[o].import_runs(h_o, rec[c0:c0 + recs[o]].contiguous(), None if tw is None else tw[c0:c0 + recs[o]].contiguous())
+            tot_runs[o] += runs[o]
+            tot_recs[o] += recs[o]
+            r0 += runs[o]
+            c0 += recs[o]
+    assert tot_runs == whole[3] and tot_recs == whole[4]
+    got = {k: [] for k in kinds}
+    for o in range(3):
+        out = owners[o].finalize(k=20)
+        for k in kinds:
+            got[k].append(topk_to_rows(*out[k]))
+    merged = {k: tuple(np.concatenate([p[i] for p in got[k]]) for i in range(3)) for k in kinds}
+    _assert_rows_equal(merged, want, kinds)
+    with pytest.raises(Exception):
+        b.export_plan_range(bounds, 10, slots + 1)
+
+
 def test_sharded_builder_over_rccl_world_of_one(gpu_device):
     """The N > 1 code path of bench.py over the real RCCL backend with a world of one process: the all-to-all-v writes the
     records straight into the owner context (otto_covis_import_reserve), no staging. Rows == single-context build."""
