@@ -222,9 +222,11 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
             __syncthreads();
             CD_PH(3);
             const int hw = tid >> 5, l = tid & 31;
-            // One half-wave per list, GU lists in flight per half-wave: the list rows come from global memory (L2 at best) and a
-            // half-wave that waits for one row at a time spends the gather in load latency (a long session concatenates several
-            // hundred lists: 20+ dependent round trips per half-wave); the inserts of a batch start when its rows have arrived.
+            // One half-wave per list, GU lists in flight per half-wave (the rows come from global memory; the inserts of a batch
+            // start when its rows have arrived). Round-3 measurements on the click recipe (111 - 118 ms run to run): rows in
+            // flight 1 -> 4, the per-wave distinct counter, double hashing and list sizes from ballots each left it unchanged --
+            // the gather + insert phase (47 - 56 % of the long-session kernel in the diagnostic build) is bound by none of the
+            // list loads, the same-address counter or the probe chains alone.
             constexpr int GU = 4;
             constexpr uint32_t HWS = CD_THREADS / 32;
             const uint32_t sweeps = s_maxlen > 32u ? (s_maxlen + 31u) / 32u : 1u;      // lists longer than 32 (neighbour lists): more sweeps
@@ -268,7 +270,9 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                             const uint32_t step = ((y * 0x85EBCA6Bu) >> (32 - lt)) | 1u;
                             bool placed = false;
                             for (int probe = 0; probe < Teff; ++probe) {
-                                // CAS first: a new aid goes in together with its first count
+                                // CAS first: a new aid goes in together with its first count. (Measured and dropped in round 3: a
+                                // plain read before the atomics, so that a hit costs one atomic add instead of a failed CAS + add
+                                // + min on its slot: click recipe 115 -> 127 ms.)
                                 const unsigned long long old = atomicCAS(&s_tab[slot], (unsigned long long)CD_EMPTY, ((unsigned long long)y << 32) | 1ull);
                                 const bool fresh = old == CD_EMPTY;
                                 if (fresh || (uint32_t)(old >> 32) == y) {
@@ -285,8 +289,8 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                         }
                         nfr += (uint32_t)__popcll(__ballot(fr));
                     }
-                    // distinct aids of the partition so far: ONE LDS atomic per wave and batch (a counter bumped by every new key
-                    // is a 64-way same-address conflict per wave-instruction: it was the long sessions' largest single cost)
+                    // distinct aids of the partition so far: ONE LDS atomic per wave and batch instead of one per new key on the
+                    // same address
                     if (TOT > (uint32_t)CD_CAP && nfr != 0 && (tid & 63) == 0 && atomicAdd(&s_nfresh, nfr) + nfr > (uint32_t)CD_CAP) s_ovf = 1;
                 }
             }
