@@ -3277,6 +3277,13 @@ struct otto_covis_ctx {
     int items_allow_packed = -1;   // layout rule the L item list was built with (-1: not built)
     DevBuf tau_w, tau_y;           // threshold guesses of partitioned heavy aids (per reduce pass)
     int guess = 1;                 // option "guess": single-pass top-k from a sibling partition's threshold
+    hipStream_t side = nullptr;    // the partition pass of the heavy aids runs here, beside the S / M bins
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool part_early = false;       // the partition of this pass is in flight on `side`
+    int overlap_partition = 0;     // option "overlap_partition": measured at full OTTO shape, both kernels take twice as long side by
+                                   // side (partition 3.8 -> 6.2 ms, reduce S 2.9 -> 6.3 ms: the S bin's 20 workgroups per CU leave the
+                                   // partition workgroups no LDS), the step gains 0.4 ms of 31.5 and the per-kernel times stop adding up:
+                                   // off by default
     int hot = 2;                   // option "hot": 1 = top-k walks of the multi-wave bins over the heavy keys only, 2 = + single-wave
                                    // selection when the heavy keys are few (M bin), 0 = off (A/B)
     DevBuf exp_run_pos, exp_rec_pos, exp_totals;
@@ -3329,6 +3336,10 @@ extern "C" int otto_covis_create(otto_covis_ctx** out, const otto_covis_params* 
     c->ev_ok = true;
     for (int i = 0; i < 2 * OTTO_COVIS_T_COUNT; ++i)
         if (hipEventCreate(&c->ev[i]) != hipSuccess) c->ev_ok = false;
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        c->side = nullptr;                                  // no side stream: the partition stays on the caller's stream
+    }
     memset(c->ev_set, 0, sizeof c->ev_set);
     *out = c;
     return 0;
@@ -3345,6 +3356,9 @@ extern "C" void otto_covis_destroy(otto_covis_ctx* c) {
     for (DevBuf* b : all) b->release();
     if (c->ev_ok)
         for (int i = 0; i < 2 * OTTO_COVIS_T_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     delete c;
 }
 
@@ -3716,6 +3730,50 @@ static void reduce_name(otto_covis_ctx* c, int slot, int log2t, int threads, int
             k_reduce<__VA_ARGS__, 1, false><<<grid, threads, 0, s>>>(args);                            \
     } while (0)
 
+// bucket the records of the partitioned heavy aids by hash partition (a: the L item list of this pass). Leaves pstart / pcursor /
+// prec (/ ptw) in the context. Synchronises `s` once (bucket total -> allocation).
+static int run_partition(otto_covis_ctx* c, const ReduceArgs& a, bool time, hipStream_t s) {
+            // bucket the records of heavy aids by hash partition once (count -> scan -> scatter)
+    tbegin(c, OTTO_COVIS_T_PARTITION, s);
+    OTTO_TRY(c->pcount.ensure((size_t)a.n_items * 4, 0, s));
+    OTTO_TRY(c->pcursor.ensure((size_t)a.n_items * 4, 0, s));
+    OTTO_TRY(c->pstart.ensure((size_t)(a.n_items + 1) * 8, 0, s));
+    OTTO_TRY(c->partial.ensure(scan_partial_bytes((int64_t)a.n_items), 0, s));
+    OTTO_HIP(hipMemsetAsync(c->pcursor.p, 0, (size_t)a.n_items * 4, s));
+    PartArgs pa{c->chunks.as<uint64_t>(), (uint32_t)c->n_chunks, c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(),
+                c->run_start.as<uint64_t>(), c->sorted_desc.as<uint64_t>(), c->rec.as<uint32_t>(), c->tw.as<uint32_t>(),
+                c->litem_start.as<uint64_t>(), c->pcount.as<uint32_t>(), c->pcursor.as<uint32_t>(),
+                c->pstart.as<uint64_t>(), nullptr, nullptr, c->l_cap, c->p.window, a.allow_packed, c->flag.as<uint32_t>(),
+                c->counters.as<uint32_t>()};
+    const uint32_t pgrid = (uint32_t)(c->n_chunks < 256u * 5u ? c->n_chunks : 256u * 5u);
+    const uint32_t cgrid = (uint32_t)(c->n_chunks < 256u * 8u ? c->n_chunks : 256u * 8u);
+    // First attempt: buckets sized from the record counts the index already holds (2 x mean + margin), no count pass.
+    // Retry rounds (aids whose bucket or LDS table overflowed): counted buckets, exact.
+    const bool sized = c->part_sized && !c->exact_round;
+    if (sized) {
+        kname(c, OTTO_COVIS_T_PARTITION, "k_partition<true>");
+        OTTO_TRY(device_scan(ItemCap{a.items, c->cnt64.as<uint64_t>()}, (int64_t)a.n_items, c->pstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+    } else {
+        kname(c, OTTO_COVIS_T_PARTITION, "k_partition<false> + k_partition<true>");
+        OTTO_HIP(hipMemsetAsync(c->pcount.p, 0, (size_t)a.n_items * 4, s));
+        k_partition<false, false><<<cgrid, 256, 0, s>>>(pa);
+        OTTO_HIP(hipGetLastError());
+        OTTO_TRY(device_scan(PCount{c->pcount.as<uint32_t>()}, (int64_t)a.n_items, c->pstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+    }
+    uint64_t bucket_total = 0;
+    OTTO_HIP(hipMemcpyAsync(&bucket_total, c->pstart.as<uint64_t>() + a.n_items, 8, hipMemcpyDeviceToHost, s));
+    OTTO_HIP(hipStreamSynchronize(s));
+    OTTO_TRY(c->prec.ensure((size_t)(bucket_total ? bucket_total : 1) * 4, 0, s));
+    if (time) OTTO_TRY(c->ptw.ensure((size_t)(bucket_total ? bucket_total : 1) * 4, 0, s));
+    pa.prec = c->prec.as<uint32_t>();
+    pa.ptw = time ? c->ptw.as<uint32_t>() : nullptr;
+    if (time) k_partition<true, true><<<pgrid, 256, 0, s>>>(pa);
+    else k_partition<true, false><<<pgrid, 256, 0, s>>>(pa);
+    OTTO_HIP(hipGetLastError());
+    tend(c, OTTO_COVIS_T_PARTITION, s);
+    return 0;
+}
+
 template <int GROUP>
 static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s) {
     a.items = c->items[bin].as<uint64_t>();
@@ -3764,45 +3822,13 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
     } else {
         a.pstart = nullptr;
         if (c->partition && c->n_chunks) {
-            // bucket the records of heavy aids by hash partition once (count -> scan -> scatter)
-            tbegin(c, OTTO_COVIS_T_PARTITION, s);
-            const bool time = GROUP == OTTO_COVIS_GROUP_TIME;
-            OTTO_TRY(c->pcount.ensure((size_t)a.n_items * 4, 0, s));
-            OTTO_TRY(c->pcursor.ensure((size_t)a.n_items * 4, 0, s));
-            OTTO_TRY(c->pstart.ensure((size_t)(a.n_items + 1) * 8, 0, s));
-            OTTO_TRY(c->partial.ensure(scan_partial_bytes((int64_t)a.n_items), 0, s));
-            OTTO_HIP(hipMemsetAsync(c->pcursor.p, 0, (size_t)a.n_items * 4, s));
-            PartArgs pa{c->chunks.as<uint64_t>(), (uint32_t)c->n_chunks, c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(),
-                        c->run_start.as<uint64_t>(), c->sorted_desc.as<uint64_t>(), c->rec.as<uint32_t>(), c->tw.as<uint32_t>(),
-                        c->litem_start.as<uint64_t>(), c->pcount.as<uint32_t>(), c->pcursor.as<uint32_t>(),
-                        c->pstart.as<uint64_t>(), nullptr, nullptr, c->l_cap, c->p.window, a.allow_packed, c->flag.as<uint32_t>(),
-                        c->counters.as<uint32_t>()};
-            const uint32_t pgrid = (uint32_t)(c->n_chunks < 256u * 5u ? c->n_chunks : 256u * 5u);
-            const uint32_t cgrid = (uint32_t)(c->n_chunks < 256u * 8u ? c->n_chunks : 256u * 8u);
-            // First attempt: buckets sized from the record counts the index already holds (2 x mean + margin), no count pass.
-            // Retry rounds (aids whose bucket or LDS table overflowed): counted buckets, exact.
-            const bool sized = c->part_sized && !c->exact_round;
-            if (sized) {
-                kname(c, OTTO_COVIS_T_PARTITION, "k_partition<true>");
-                OTTO_TRY(device_scan(ItemCap{a.items, c->cnt64.as<uint64_t>()}, (int64_t)a.n_items, c->pstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+            if (c->part_early) {
+                // launched on the side stream before the S / M bins (otto_covis_finalize): the heavy bin waits for it here
+                OTTO_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
+                c->part_early = false;
             } else {
-                kname(c, OTTO_COVIS_T_PARTITION, "k_partition<false> + k_partition<true>");
-                OTTO_HIP(hipMemsetAsync(c->pcount.p, 0, (size_t)a.n_items * 4, s));
-                k_partition<false, false><<<cgrid, 256, 0, s>>>(pa);
-                OTTO_HIP(hipGetLastError());
-                OTTO_TRY(device_scan(PCount{c->pcount.as<uint32_t>()}, (int64_t)a.n_items, c->pstart.as<uint64_t>(), c->partial.as<uint64_t>(), s));
+                OTTO_TRY(run_partition(c, a, GROUP == OTTO_COVIS_GROUP_TIME, s));
             }
-            uint64_t bucket_total = 0;
-            OTTO_HIP(hipMemcpyAsync(&bucket_total, c->pstart.as<uint64_t>() + a.n_items, 8, hipMemcpyDeviceToHost, s));
-            OTTO_HIP(hipStreamSynchronize(s));
-            OTTO_TRY(c->prec.ensure((size_t)(bucket_total ? bucket_total : 1) * 4, 0, s));
-            if (time) OTTO_TRY(c->ptw.ensure((size_t)(bucket_total ? bucket_total : 1) * 4, 0, s));
-            pa.prec = c->prec.as<uint32_t>();
-            pa.ptw = time ? c->ptw.as<uint32_t>() : nullptr;
-            if (time) k_partition<true, true><<<pgrid, 256, 0, s>>>(pa);
-            else k_partition<true, false><<<pgrid, 256, 0, s>>>(pa);
-            OTTO_HIP(hipGetLastError());
-            tend(c, OTTO_COVIS_T_PARTITION, s);
             a.pstart = c->pstart.as<uint64_t>();
             a.pcursor = c->pcursor.as<uint32_t>();
             a.prec = c->prec.as<uint32_t>();
@@ -3935,6 +3961,19 @@ extern "C" int otto_covis_finalize(otto_covis_ctx* c, int group, int k, uint32_t
                 a.part_w = c->part_w.as<uint64_t>();
             }
             if (first) {
+                // the partition pass of the heavy aids (a gather that waits on memory) beside the S and M bins (LDS atomics):
+                // forked onto the side stream behind everything queued so far, joined where the heavy bin starts
+                if (c->overlap_partition && c->side && c->partition && c->n_chunks && c->n_items[2]) {
+                    ReduceArgs ap = a;
+                    ap.items = c->items[2].as<uint64_t>();
+                    ap.n_items = (uint32_t)c->n_items[2];
+                    ap.allow_packed = c->items_allow_packed > 0 ? c->items_allow_packed : 0;
+                    OTTO_HIP(hipEventRecord(c->ev_fork, s));
+                    OTTO_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+                    OTTO_TRY(run_partition(c, ap, group == OTTO_COVIS_GROUP_TIME, c->side));
+                    OTTO_HIP(hipEventRecord(c->ev_join, c->side));
+                    c->part_early = true;
+                }
                 OTTO_TRY(launch_reduce_group(c, a, 0, s));
                 OTTO_TRY(launch_reduce_group(c, a, 1, s));
             }
@@ -3972,6 +4011,7 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
     if (strcmp(name, "bucket_index") == 0) { c->bucket_index = value != 0; return 0; }
     if (strcmp(name, "guess") == 0) { c->guess = value != 0; return 0; }           // threshold guessing on/off (A/B)
     if (strcmp(name, "fused") == 0) { c->fused = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return 0; }   // 2 component lists, 1 fused register rows, 0 class-sorted kernels (A/B)
+    if (strcmp(name, "overlap_partition") == 0) { c->overlap_partition = value != 0; return 0; }
     if (strcmp(name, "hot") == 0) { c->hot = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return 0; }
     if (strcmp(name, "fast_path") == 0) { c->fast_path = value != 0; return 0; }   // gap-free window kernel on/off (A/B)
     if (strcmp(name, "part_sized") == 0) { c->part_sized = value != 0; return 0; }   // A/B: counted buckets only
