@@ -3270,6 +3270,7 @@ struct otto_covis_ctx {
     DevBuf part_y, part_w;
     DevBuf bcount, bstart, tmp_runs;          // bucketed index
     int bucket_index = 1;          // option "bucket_index": LDS-atomic index build (0 = global-atomic histogram)
+    int bkt_sh = 0;                // option "bkt_sh": log2 aids per index bucket (0 = from the aid space)
     DevBuf lorder[3][3], lrank, lmode_start;   // [bin][mode] processing order of the tiers / layouts (heavy: pilots first)
     uint64_t n_order[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     int packed_heavy = 2;          // option "packed_heavy": packed layout for heavy aids with < 4096 runs (1: 2^14 tables for every aid
@@ -3617,9 +3618,12 @@ static int build_index(otto_covis_ctx* c, hipStream_t s) {
     while ((1ull << aid_bits) < (uint64_t)n_aids) ++aid_bits;
     BktArgs ba;
     memset(&ba, 0, sizeof ba);
-    // ~256 buckets where the aid space allows it: the pieces a 16 k-run chunk sends to one bucket are then ~64 runs long (full
-    // cache lines); buckets of at most 2^13 aids (the record's 13 bits, 96 KB of LDS in k_bkt_fused)
-    ba.sh = aid_bits - 8 < 10 ? 10 : (aid_bits - 8 > BKT_MAX_SH ? BKT_MAX_SH : aid_bits - 8);
+    // ~1000 buckets where the aid space allows it (measured at OTTO shape, 2^21 aids: buckets of 2^10 / 2^11 / 2^12 / 2^13 aids ->
+    // index 2.95 / 3.05 / 3.1 / 3.3 ms: a bucket's runs (1 - 2 MB) should stay inside one XCD's L2 between the count walk, the
+    // place walk and its scattered 8-byte stores; the pieces a 16 k-run chunk sends to a bucket are still 16 - 18 runs long);
+    // buckets of at most 2^13 aids (the record's 13 bits, 96 KB of LDS in k_bkt_fused)
+    ba.sh = aid_bits - 10 < 10 ? 10 : (aid_bits - 10 > BKT_MAX_SH ? BKT_MAX_SH : aid_bits - 10);
+    if (c->bkt_sh >= 8 && c->bkt_sh <= BKT_MAX_SH) ba.sh = c->bkt_sh;                 // option "bkt_sh" (A/B)
     ba.nb = (uint32_t)(((uint64_t)n_aids + (1ull << ba.sh) - 1) >> ba.sh);
     const bool bucketed = c->bucket_index && n_slots > 0 && n_slots < (1ll << 32) && ba.nb <= (uint32_t)BKT_MAX_NB;
     if (bucketed) {
@@ -4011,6 +4015,7 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
     if (strcmp(name, "bucket_index") == 0) { c->bucket_index = value != 0; return 0; }
     if (strcmp(name, "guess") == 0) { c->guess = value != 0; return 0; }           // threshold guessing on/off (A/B)
     if (strcmp(name, "fused") == 0) { c->fused = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return 0; }   // 2 component lists, 1 fused register rows, 0 class-sorted kernels (A/B)
+    if (strcmp(name, "bkt_sh") == 0) { c->bkt_sh = (int)value; c->index_valid = false; return 0; }
     if (strcmp(name, "overlap_partition") == 0) { c->overlap_partition = value != 0; return 0; }
     if (strcmp(name, "hot") == 0) { c->hot = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return 0; }
     if (strcmp(name, "fast_path") == 0) { c->fast_path = value != 0; return 0; }   // gap-free window kernel on/off (A/B)
