@@ -2004,7 +2004,12 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         const uint64_t item = cur.item;
         const uint32_t x = (uint32_t)(item & REC_AID_MASK);
         const uint32_t part = (uint32_t)((item >> 26) & 0xFFFFFFu);
-        const int lgR = (int)(item >> 50);
+        // only the heavy bin's items are hash partitions: for the M instantiation lgR is the constant 0, so the guess path, the
+        // bucket reads, the partial lists and the partition filter of the gather compile away -- the M kernel sits at its 128-VGPR
+        // cap, every path it does not need is registers back (scratch 8 -> 0 bytes, 6.6 -> 6.27 ms). (The one-wave S kernel also
+        // never sees a partition, but with the constant it got SLOWER, 2.85 -> 2.98 ms at 73 instead of 85 VGPRs: left as it was.)
+        constexpr bool CAN_PART = THREADS != M_THREADS;
+        const int lgR = CAN_PART ? (int)(item >> 50) : 0;
         const uint32_t pmask = (1u << lgR) - 1u;
         const int pshift = 32 - LOG2T - lgR;
 
@@ -3270,6 +3275,7 @@ struct otto_covis_ctx {
     DevBuf part_y, part_w;
     DevBuf bcount, bstart, tmp_runs;          // bucketed index
     int bucket_index = 1;          // option "bucket_index": LDS-atomic index build (0 = global-atomic histogram)
+    int s_wgs = 20;                // option "s_wgs": one-wave workgroups of the S bin per CU (A/B)
     int bkt_sh = 0;                // option "bkt_sh": log2 aids per index bucket (0 = from the aid space)
     DevBuf lorder[3][3], lrank, lmode_start;   // [bin][mode] processing order of the tiers / layouts (heavy: pilots first)
     uint64_t n_order[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -3810,7 +3816,8 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
     auto prof_end = [&](const char*, uint32_t) {};
 #endif
     if (bin == 0) {
-        uint32_t grid = a.n_items < 256u * 20u ? a.n_items : 256u * 20u;
+        const uint32_t s_res = 256u * (uint32_t)c->s_wgs;
+        uint32_t grid = a.n_items < s_res ? a.n_items : s_res;
         tbegin(c, OTTO_COVIS_T_REDUCE_S, s);
         prof_begin();
         OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_S, grid, S_THREADS, a, S_LOG2T, S_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, 5, 4);
@@ -4015,6 +4022,7 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
     if (strcmp(name, "bucket_index") == 0) { c->bucket_index = value != 0; return 0; }
     if (strcmp(name, "guess") == 0) { c->guess = value != 0; return 0; }           // threshold guessing on/off (A/B)
     if (strcmp(name, "fused") == 0) { c->fused = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return 0; }   // 2 component lists, 1 fused register rows, 0 class-sorted kernels (A/B)
+    if (strcmp(name, "s_wgs") == 0) { c->s_wgs = value < 1 ? 1 : (value > 32 ? 32 : (int)value); return 0; }
     if (strcmp(name, "bkt_sh") == 0) { c->bkt_sh = (int)value; c->index_valid = false; return 0; }
     if (strcmp(name, "overlap_partition") == 0) { c->overlap_partition = value != 0; return 0; }
     if (strcmp(name, "hot") == 0) { c->hot = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return 0; }
