@@ -890,6 +890,7 @@ __global__ __launch_bounds__(256, 4) void k_expand_lists(ExpandArgs a, int64_t n
 // ---------------------------------------------------------------------------
 // index: histogram / scatter of runs by aid_x, work items
 // ---------------------------------------------------------------------------
+constexpr uint64_t REC_PAD = 64;                      // words past the last record slot that may be READ (for_each_record_seg: lanes without a record)
 constexpr int CNT_REC_BITS = 36;                      // cnt64[x] = runs << 36 | records
 constexpr uint64_t CNT_REC_MASK = (1ull << CNT_REC_BITS) - 1;
 
@@ -1440,7 +1441,7 @@ template <int NW, int GATHER_U, bool NEED_SL, typename FB>
 __device__ __forceinline__ void for_each_record_seg(const uint64_t* sorted_desc, const uint32_t* rec, uint64_t r0, uint64_t r1,
                                                     int wid, uint8_t* s_seg, FB fb) {
     const unsigned lane = lane_id();
-    const uint32_t g = lane >> 3, gl = lane & 7u;
+    const uint32_t g = lane >> 3, gl4 = (lane & 7u) << 2;
     if (r0 >= r1) return;
     auto load_desc = [&](uint64_t cb) {
         const uint64_t mine = cb + (uint64_t)lane * NW + wid;
@@ -1456,25 +1457,41 @@ __device__ __forceinline__ void for_each_record_seg(const uint64_t* sorted_desc,
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k)
-            if (k < segs) s_seg[excl + k] = (uint8_t)(lane | (k << 6));      // descriptor lane | segment of the run (len <= 32: 4 segments)
+            if (k < segs) s_seg[excl + k] = (uint8_t)((lane << 2) | k);      // descriptor lane << 2 | segment of the run (len <= 32: 4 segments)
         wave_lds_sync();
         const int nstep = (int)((total + 7u) >> 3);
+        // what a record's lane needs of its run, in the two words it fetches from the descriptor lane: the ADDRESS of the
+        // run's first record (48 bits) with len and sp in the 16 bits above it -- per record 2 field extracts, 1 mask and
+        // 1 add instead of unpacking the descriptor (slot shift, masks, base add, offset add) 64 times per run chunk
+        const uint64_t recb = (uint64_t)(uintptr_t)rec;
+        const uint64_t pre = (recb + (desc_slot(d) << 2)) | ((uint64_t)desc_len(d) << 50) | ((uint64_t)desc_sp(d) << 58);   // len * 4, sp * 4 in bytes 6, 7
+        const int plo = (int)(uint32_t)pre, phi = (int)(uint32_t)(pre >> 32);
         uint32_t rcA[GATHER_U], rcB[GATHER_U];
         uint64_t slA[NEED_SL ? GATHER_U : 1], slB[NEED_SL ? GATHER_U : 1];
-        bool okA[GATHER_U], okB[GATHER_U];
-        auto issue = [&](int t, uint32_t (&rc)[GATHER_U], uint64_t (&sl)[NEED_SL ? GATHER_U : 1], bool (&ok)[GATHER_U]) {
+        uint64_t okA[GATHER_U], okB[GATHER_U];                              // wave masks (SGPR pairs): lanes that hold a record
+        // Branch-free on purpose -- one basic block, so the GATHER_U segment reads, the 2 x GATHER_U descriptor permutes and
+        // the loads go out back to back instead of one dependent LDS round trip after the other: the segment byte is read
+        // whether or not the step has a segment for this group (stale bytes name some lane of the wave, whose descriptor is a
+        // real one or 0: the step bound masks the result), and a lane without a record still loads the word its (run, offset)
+        // names -- at most 31 words past a run, inside the 64-word pad every rec allocation carries (REC_PAD; tw is only
+        // read where a record is). The three conditions are compares straight into wave masks, combined on the scalar unit.
+        constexpr int ICMP_NE = 33, ICMP_ULT = 36, ICMP_SLT = 40;
+        auto issue = [&](int t, uint32_t (&rc)[GATHER_U], uint64_t (&sl)[NEED_SL ? GATHER_U : 1], uint64_t (&ok)[GATHER_U]) {
+            const uint32_t qb = (uint32_t)t * 8u + g;
+            const int lim = (int)total - 8 * t;                              // group g of step t + u has a segment: g < lim - 8 u
 #pragma unroll
             for (int u = 0; u < GATHER_U; ++u) {
-                const uint32_t q = (uint32_t)(t + u) * 8u + g;
-                const bool has = q < total;
-                const uint32_t r = has ? (uint32_t)s_seg[q] : 0u;
-                const uint64_t dd = (uint64_t)__shfl((unsigned long long)d, (int)(r & 63u), 64);
-                const uint32_t off = (r >> 6) * 8u + gl;
-                const uint32_t sp = desc_sp(dd);
-                const uint64_t s0 = desc_slot(dd);
-                if (NEED_SL) sl[NEED_SL ? u : 0] = s0 + (sp != DESC_SP_NONE ? sp : off);   // where the record's time extra lives
-                ok[u] = has && off < desc_len(dd) && off != sp;                // the run's own list entry is not a pair
-                rc[u] = ok[u] ? rec[s0 + off] : 0u;
+                const uint32_t r = (uint32_t)s_seg[qb + 8u * u];             // (t + u) * 8 + g < 256 + 8 * GATHER_U: the array is padded
+                const int src = (int)(r & 0xFCu);                            // ds_bpermute: byte address = lane * 4
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, plo);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, phi);
+                const uint32_t off4 = ((r & 3u) << 5) | gl4;                 // byte offset of the lane's record in the run
+                const uint32_t len4 = (hi >> 16) & 0xFFu, sp4 = hi >> 24;
+                const uint64_t base = ((uint64_t)(hi & 0xFFFFu) << 32) | lo;
+                if (NEED_SL) sl[NEED_SL ? u : 0] = (base - recb + (sp4 != DESC_SP_NONE * 4u ? sp4 : off4)) >> 2;   // where the record's time extra lives
+                ok[u] = __builtin_amdgcn_sicmp((int)g, lim - 8 * u, ICMP_SLT) & __builtin_amdgcn_uicmp(off4, len4, ICMP_ULT) &
+                        __builtin_amdgcn_uicmp(off4, sp4, ICMP_NE);          // the run's own list entry is not a pair
+                rc[u] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>((uintptr_t)(base + off4));
             }
         };
         if (nstep > 0) issue(0, rcA, slA, okA);
@@ -1552,7 +1569,7 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
     __shared__ uint32_t s_stage_tw[(SCATTER && TW) ? PART_STAGE : 1];
     __shared__ uint32_t s_full;                        // a capacity-sized bucket of this chunk's aid is full
     __shared__ uint32_t s_n;                           // records staged so far
-    __shared__ uint8_t s_seg[NW][256];                 // gather: segment -> descriptor lane, per wave
+    __shared__ uint8_t s_seg[NW * 256 + 32];           // gather: segment -> descriptor lane, per wave (+ pad: for_each_record_seg reads past a wave's last segment)
     const int wid = threadIdx.x >> 6;
     for (uint32_t ci = blockIdx.x; ci < a.n_chunks; ci += gridDim.x) {
         const uint64_t ch = a.chunks[ci];
@@ -1601,16 +1618,16 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
             // ONE pass over the chunk's records: they land in the LDS stage in arrival order (wave-aggregated cursor)
             // while the per-partition histogram is taken; the scatter then reads them back from LDS
             const unsigned lane = lane_id();
-            for_each_record_seg<NW, 4, TW>(a.sorted_desc, a.rec, rb, re, wid, s_seg[wid], [&](uint32_t (&rc)[4], uint64_t (&sl)[TW ? 4 : 1], bool (&ok)[4]) {
+            for_each_record_seg<NW, 4, TW>(a.sorted_desc, a.rec, rb, re, wid, s_seg + wid * 256, [&](uint32_t (&rc)[4], uint64_t (&sl)[TW ? 4 : 1], uint64_t (&ok)[4]) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const uint64_t m = __ballot(ok[u]);
+                    const uint64_t m = ok[u];
                     if (m == 0) continue;
                     const int leader = __ffsll((unsigned long long)m) - 1;
                     uint32_t base = 0;
                     if ((int)lane == leader) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
                     base = (uint32_t)__shfl((int)base, leader, 64);
-                    if (ok[u]) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(m)) {
                         const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                         s_stage[SCATTER ? pos : 0] = rc[u];
                         if (TW) s_stage_tw[(SCATTER && TW) ? pos : 0] = a.tw[sl[TW ? u : 0]];
@@ -1883,7 +1900,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     __shared__ uint32_t s_ovf;
     constexpr int LISTCAP = BOUND ? S_CAP : 256;
     __shared__ uint16_t s_list[NW == 1 ? LISTCAP : 1];                         // one-wave bins: compacted valid slots
-    __shared__ uint8_t s_seg[NW][256];                                         // gather: segment -> descriptor lane, per wave
+    __shared__ uint8_t s_seg[NW * 256 + 32];                                   // gather: segment -> descriptor lane, per wave (+ pad: the gather reads past a wave's last segment)
     __shared__ ItemDesc s_cur;
     __shared__ ItemDesc s_nxt;                                                // the item after s_cur (for the record prefetch)
 
@@ -2044,14 +2061,16 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         // a wave-private counter and the ballot rank: no LDS atomic, no round trip (every lane of the wave calls this
         // together; lanes that claim a slot later, inside a probe loop, report it after the loop through the same call)
         uint32_t wc = 0;
-        auto note_new = [&](bool isnew, uint32_t slot) {
+        // m: wave mask of the lanes whose key is new (compares go straight into wave masks: a bool would be materialised in a
+        // register and compared again)
+        auto note_new = [&](uint64_t m, uint32_t slot) {
             if (NW == 1) return;
-            const uint64_t m = __ballot(isnew);
             if (m == 0) return;
             const uint32_t pos = wc + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (isnew && pos < (uint32_t)RCAP) s_occ[NW > 1 ? wid * RCAP + pos : 0] = (uint16_t)slot;
+            if (__builtin_amdgcn_inverse_ballot_w64(m) && pos < (uint32_t)RCAP) s_occ[NW > 1 ? wid * RCAP + pos : 0] = (uint16_t)slot;
             wc += (uint32_t)__popcll(m);
         };
+        constexpr int ICMP_EQ = 32, ICMP_NE = 33;
         // Double hashing: the probe step is a second hash of the key (odd: every slot is visited in T probes). Linear probing
         // builds clusters, and a wave waits for its longest chain: every probe is a dependent LDS round trip.
         // returns the slot it claimed for a NEW key, else 0xFFFFFFFF
@@ -2097,27 +2116,30 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         };
         // CH records per lane are in flight at a time (more would spill: the 2^14 kernel runs at 128 VGPRs); a chunk no
         // lane of the wave has a record for is skipped as a whole (small aids: most of a gather batch is empty)
-        auto insert_batch = [&](auto ntag, const uint32_t* rc, const bool* okin, const uint32_t* e) {
+        auto insert_batch = [&](auto ntag, const uint32_t* rc, const uint64_t* okin, const uint32_t* e) {     // okin: wave masks
             constexpr int N = decltype(ntag)::value;
             constexpr int CH = INS_CH;
             if (DBG && (a.debug_skip & 8)) {                 // diagnostics: records are fetched but not inserted
 #pragma unroll
                 for (int u = 0; u < N; ++u)
-                    if (okin[u] && rc[u] == 0xDEADBEEFu) s_ovf = 1;
+                    if (__builtin_amdgcn_inverse_ballot_w64(okin[u]) && rc[u] == 0xDEADBEEFu) s_ovf = 1;
                 return;
             }
 #pragma unroll
             for (int c0 = 0; c0 < N; c0 += CH) {
                 bool ok[CH];
-                bool any = false;
+                uint64_t okm[CH];
+                uint64_t any = 0;
 #pragma unroll
                 for (int q = 0; q < CH; ++q) {
                     const int u = c0 + q;
-                    ok[q] = u < N && okin[u < N ? u : 0];
-                    if (GROUP == OTTO_COVIS_GROUP_FILTER && ok[q] && (((rc[u < N ? u : 0] >> 28) >> a.chan_shift) & 7u) == 0u) ok[q] = false;
-                    any = any || ok[q];
+                    uint64_t m = u < N ? okin[u < N ? u : 0] : 0ull;
+                    if (GROUP == OTTO_COVIS_GROUP_FILTER) m &= __builtin_amdgcn_uicmp(((rc[u < N ? u : 0] >> 28) >> a.chan_shift) & 7u, 0u, ICMP_NE);
+                    okm[q] = m;
+                    ok[q] = __builtin_amdgcn_inverse_ballot_w64(m);
+                    any |= m;
                 }
-                if (__ballot(any) == 0) continue;
+                if (any == 0) continue;
                 if (PACKED) {
                     uint32_t oldhi[CH];                       // high word of the slot before the CAS: 0xFFFFFFFF = was empty
                     unsigned long long addq[CH];              // the record's counter increment, built once
@@ -2132,7 +2154,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                                                                    ((unsigned long long)(r & REC_AID_MASK) << 36) | addq[q]);
                             oldhi[q] = (uint32_t)(o >> 32);
                         }
-                        note_new(ok[q] && oldhi[q] == 0xFFFFFFFFu, slot);
+                        note_new(okm[q] & __builtin_amdgcn_uicmp(oldhi[q], 0xFFFFFFFFu, ICMP_EQ), slot);
                     }
 #pragma unroll
                     for (int q = 0; q < CH; ++q) {
@@ -2144,7 +2166,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                             if ((oldhi[q] >> 4) == y) atomicAdd((unsigned long long*)&s_tab[PACKED ? slot : 0], addq[q]);
                             else late = probe_on(y, slot, addq[q], (unsigned long long)y << 36);
                         }
-                        note_new(late != 0xFFFFFFFFu, late);
+                        note_new(__builtin_amdgcn_uicmp(late, 0xFFFFFFFFu, ICMP_NE), late);
                     }
                     continue;
                 }
@@ -2154,7 +2176,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                     const uint32_t r = rc[c0 + q < N ? c0 + q : 0];
                     old[q] = KEY_EMPTY;
                     if (ok[q]) old[q] = atomicCAS(&s_key[PACKED ? 0 : rec_hash(r) >> (32 - LOG2T)], KEY_EMPTY, r & REC_AID_MASK);
-                    note_new(ok[q] && old[q] == KEY_EMPTY, rec_hash(r) >> (32 - LOG2T));
+                    note_new(okm[q] & __builtin_amdgcn_uicmp(old[q], KEY_EMPTY, ICMP_EQ), rec_hash(r) >> (32 - LOG2T));
                 }
 #pragma unroll
                 for (int q = 0; q < CH; ++q) {
@@ -2174,7 +2196,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                         if (!found) s_ovf = 1;
                         else wide_add(r, sl, e[c0 + q < N ? c0 + q : 0]);
                     }
-                    note_new(late != 0xFFFFFFFFu, late);
+                    note_new(__builtin_amdgcn_uicmp(late, 0xFFFFFFFFu, ICMP_NE), late);
                 }
             }
         };
@@ -2237,22 +2259,23 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (threadIdx.x == 0) { const unsigned long long _t = clock64(); ph[12] += _t - ph_t; ph[2] -= _t - ph_t; }   // p2 = inserts only; ph[12] = wait for the records
 #endif
-                bool okb[BU];
+                uint64_t okb[BU];
 #pragma unroll
-                for (int u = 0; u < BU; ++u) okb[u] = rc[u] != KEY_EMPTY;
+                for (int u = 0; u < BU; ++u) okb[u] = __ballot(rc[u] != KEY_EMPTY);
                 insert_batch(std::integral_constant<int, BU>{}, rc, okb, e);
                 if (s_ovf) break;
             }
         } else {
             constexpr bool NEED_SL = GROUP == OTTO_COVIS_GROUP_TIME;
-            for_each_record_seg<NW, GU, NEED_SL>(a.sorted_desc, a.rec, cur.rb, cur.re, wid, s_seg[wid],
-                                                 [&](uint32_t (&rc)[GU], uint64_t (&sl)[NEED_SL ? GU : 1], bool (&ok)[GU]) {
+            for_each_record_seg<NW, GU, NEED_SL>(a.sorted_desc, a.rec, cur.rb, cur.re, wid, s_seg + wid * 256,
+                                                 [&](uint32_t (&rc)[GU], uint64_t (&sl)[NEED_SL ? GU : 1], uint64_t (&ok)[GU]) {
                 uint32_t e[GU];
-                bool okb[GU];
+                uint64_t okb[GU];
 #pragma unroll
                 for (int u = 0; u < GU; ++u) {
-                    okb[u] = ok[u] && (lgR == 0 || ((rec_hash(rc[u]) >> pshift) & pmask) == part);
-                    e[u] = (GROUP == OTTO_COVIS_GROUP_TIME && okb[u]) ? a.tw[sl[NEED_SL ? u : 0]] : 0u;
+                    okb[u] = ok[u];
+                    if (lgR != 0) okb[u] &= __ballot(((rec_hash(rc[u]) >> pshift) & pmask) == part);
+                    e[u] = (GROUP == OTTO_COVIS_GROUP_TIME && __builtin_amdgcn_inverse_ballot_w64(okb[u])) ? a.tw[sl[NEED_SL ? u : 0]] : 0u;
                 }
                 insert_batch(std::integral_constant<int, GU>{}, rc, okb, e);
             });
@@ -3410,7 +3433,7 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
         const bool lists = c->fused == 2;                  // component lists: n list slots per window behind the pair slots
         const uint64_t n_slots = tot[0] + (lists ? n_ev : 0ull);
         OTTO_REQUIRE(c->rec_used + n_slots < (1ull << DESC_SLOT_BITS), "record slot space exhausted");
-        OTTO_TRY(c->rec.ensure((size_t)(c->rec_used + n_slots) * 4, (size_t)c->rec_used * 4, s));
+        OTTO_TRY(c->rec.ensure((size_t)(c->rec_used + n_slots + REC_PAD) * 4, (size_t)c->rec_used * 4, s));
         if (p.want_time) OTTO_TRY(c->tw.ensure((size_t)(c->rec_used + n_slots) * 4, (size_t)c->rec_used * 4, s));
         OTTO_TRY(c->run_x.ensure((size_t)(c->run_used + n_ev) * 4, (size_t)c->run_used * 4, s));
         OTTO_TRY(c->run_desc.ensure((size_t)(c->run_used + n_ev) * 8, (size_t)c->run_used * 8, s));
@@ -3479,7 +3502,7 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
     const uint64_t n_slots = totals[0], n_ev = totals[1];
     OTTO_REQUIRE(c->rec_used + n_slots < (1ull << DESC_SLOT_BITS), "record slot space exhausted");
 
-    OTTO_TRY(c->rec.ensure((size_t)(c->rec_used + n_slots) * 4, (size_t)c->rec_used * 4, s));
+    OTTO_TRY(c->rec.ensure((size_t)(c->rec_used + n_slots + REC_PAD) * 4, (size_t)c->rec_used * 4, s));
     if (p.want_time) OTTO_TRY(c->tw.ensure((size_t)(c->rec_used + n_slots) * 4, (size_t)c->rec_used * 4, s));
     OTTO_TRY(c->run_x.ensure((size_t)(c->run_used + n_ev) * 4, (size_t)c->run_used * 4, s));
     OTTO_TRY(c->run_desc.ensure((size_t)(c->run_used + n_ev) * 8, (size_t)c->run_used * 8, s));
@@ -4301,7 +4324,7 @@ extern "C" int otto_covis_import_reserve(otto_covis_ctx* c, int64_t n_recs, uint
     OTTO_REQUIRE(c && d_rec && d_tw && n_recs >= 0, "otto_covis_import_reserve: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)(n_recs > 0 ? n_recs : 1);
-    OTTO_TRY(c->rec.ensure((size_t)(c->rec_used + n) * 4, (size_t)c->rec_used * 4, s));
+    OTTO_TRY(c->rec.ensure((size_t)(c->rec_used + n + REC_PAD) * 4, (size_t)c->rec_used * 4, s));
     if (c->p.want_time) OTTO_TRY(c->tw.ensure((size_t)(c->rec_used + n) * 4, (size_t)c->rec_used * 4, s));
     *d_rec = c->rec.as<uint32_t>() + c->rec_used;
     *d_tw = c->p.want_time ? c->tw.as<uint32_t>() + c->rec_used : nullptr;
@@ -4318,7 +4341,7 @@ extern "C" int otto_covis_import_runs(otto_covis_ctx* c, const uint32_t* d_hdr, 
     OTTO_TRY(c->exp_rec_pos.ensure((size_t)(n_runs + 1) * 8, 0, s));
     OTTO_TRY(c->partial.ensure(scan_partial_bytes(n_runs), 0, s));
     OTTO_TRY(device_scan(HdrLen{d_hdr}, n_runs, c->exp_rec_pos.as<uint64_t>(), c->partial.as<uint64_t>(), s));
-    OTTO_TRY(c->rec.ensure((size_t)(c->rec_used + n_recs) * 4, (size_t)c->rec_used * 4, s));
+    OTTO_TRY(c->rec.ensure((size_t)(c->rec_used + n_recs + REC_PAD) * 4, (size_t)c->rec_used * 4, s));
     if (c->p.want_time) OTTO_TRY(c->tw.ensure((size_t)(c->rec_used + n_recs) * 4, (size_t)c->rec_used * 4, s));
     OTTO_TRY(c->run_x.ensure((size_t)(c->run_used + n_runs) * 4, (size_t)c->run_used * 4, s));
     OTTO_TRY(c->run_desc.ensure((size_t)(c->run_used + n_runs) * 8, (size_t)c->run_used * 8, s));
