@@ -1518,9 +1518,7 @@ __device__ __forceinline__ void for_each_record(const uint64_t* sorted_desc, con
     });
 }
 
-// multiplicative hash on the full-rate 24 x 24 -> 32 bit multiplier (v_mul_u32_u24; v_mul_lo_u32 issues at a quarter of the
-// rate): aid bits 24, 25 are folded onto bits 0, 1 first (keys are compared in full, the fold only costs such aids collisions)
-__device__ __forceinline__ uint32_t rec_hash(uint32_t rc) { return __umul24(rc ^ ((rc >> 24) & 3u), 0x9E3779u); }
+__device__ __forceinline__ uint32_t rec_hash(uint32_t rc) { return (rc & REC_AID_MASK) * 0x9E3779B1u; }
 
 // ---- partition pass for heavy aids (L items with R > 1): count, then scatter into per-partition buckets ----
 struct PartArgs {
@@ -2058,7 +2056,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
         // round trips in flight per lane instead of one), then hits (key already there: add) and misses (next probe) are
         // resolved. `e` = time extra (GROUP_TIME only). CAS first, no read: a new key (most records) costs ONE LDS
         // operation in the packed layout -- it goes in together with its first count.
-        auto probe_step = [&](uint32_t y) -> uint32_t { return (__umul24(__umul24(y, 0x85EBCBu) ^ (y >> 7), 0xC2B2AFu) >> (32 - LOG2T)) | 1u; };
+        auto probe_step = [&](uint32_t y) -> uint32_t { return (((y * 0x85EBCA6Bu) ^ (y >> 7)) * 0xC2B2AE35u >> (32 - LOG2T)) | 1u; };
         // a key entered the table at `slot`: append the slot to this wave's region of the dense list. The position comes from
         // a wave-private counter and the ballot rank: no LDS atomic, no round trip (every lane of the wave calls this
         // together; lanes that claim a slot later, inside a probe loop, report it after the loop through the same call)
