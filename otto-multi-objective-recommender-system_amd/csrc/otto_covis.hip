@@ -1254,7 +1254,7 @@ constexpr int MAX_KINDS = 4;
 constexpr int PK = OTTO_PK;                    // kinds reduced per pass over the records
 constexpr int PART_CHUNK_RUNS = 256;    // runs per partition-pass work item (<= 256 * 31 records: fits the LDS stage)
 constexpr int PART_STAGE = 8192;        // records staged in LDS per chunk
-constexpr int PART_STAGE_LOG2R = 10;    // staged (coalesced) scatter up to 1024 partitions, direct scatter above
+constexpr int PART_STAGE_LOG2R = 9;     // staged (coalesced) scatter up to 512 partitions (aids of <= 3.1 M pairs), direct scatter above; 10 would cost the 4th workgroup per CU (LDS)
 constexpr int PART_LDS_LOG2R = 12;      // partitions whose histogram / cursors fit LDS
 
 struct ReduceArgs {
@@ -1437,9 +1437,10 @@ __device__ __forceinline__ void for_each_record_batch(const uint64_t* sorted_des
 // OTTO run-length mix; the consumer's insert rounds -- its cost -- scale with the instructions, not the records).
 // s_seg: 256 bytes of LDS private to the wave (segment -> lane that holds the run's descriptor | segment number << 6).
 // NEED_SL: the consumer wants the record's slot (time channel lookup); otherwise the slot arrays are not kept
+// d0p: the caller already holds the wave's first 64 descriptors (requested while it was busy with something else)
 template <int NW, int GATHER_U, bool NEED_SL, typename FB>
 __device__ __forceinline__ void for_each_record_seg(const uint64_t* sorted_desc, const uint32_t* rec, uint64_t r0, uint64_t r1,
-                                                    int wid, uint8_t* s_seg, FB fb) {
+                                                    int wid, uint8_t* s_seg, FB fb, const uint64_t* d0p = nullptr) {
     const unsigned lane = lane_id();
     const uint32_t g = lane >> 3, gl4 = (lane & 7u) << 2;
     if (r0 >= r1) return;
@@ -1447,7 +1448,7 @@ __device__ __forceinline__ void for_each_record_seg(const uint64_t* sorted_desc,
         const uint64_t mine = cb + (uint64_t)lane * NW + wid;
         return mine < r1 ? sorted_desc[mine] : 0ull;
     };
-    uint64_t d = load_desc(r0);
+    uint64_t d = d0p ? *d0p : load_desc(r0);
     for (uint64_t cb = r0; cb < r1; cb += (uint64_t)NW * 64) {
         const uint64_t cbn = cb + (uint64_t)NW * 64;
         const uint64_t dn = cbn < r1 ? load_desc(cbn) : 0ull;              // next descriptors in flight
@@ -1559,112 +1560,187 @@ struct ItemCap {     // bucket capacity of L item i
 };
 
 // TW: the time channel travels with the records (GROUP_TIME): staged and scattered alongside
+// A chunk is a chain of dependent memory round trips (chunk word -> the aid's counts and run range -> its first bucket and the
+// run descriptors -> the records -> the bucket cursors) around ~13 records per thread: the SCATTER pass keeps the chain
+// of the NEXT chunks in flight while the current one is gathered and scattered (chunk word two chunks ahead, the aid's
+// words one chunk ahead, bucket base + descriptors from the middle of the current chunk). These prefetches go through the
+// VECTOR memory path on purpose (an opaque zero in the address): vector loads retire in order under vmcnt, scalar loads
+// share lgkmcnt with the LDS operations and would be waited for at the next LDS access.
 template <bool SCATTER, bool TW>
 __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
     constexpr int NW = 4;
     constexpr int RL = 1 << (SCATTER ? PART_STAGE_LOG2R : PART_LDS_LOG2R);
+    constexpr int WSTAGE = PART_STAGE / NW;            // stage region of one wave (its 64 runs x window_max records fit: `direct` below)
     __shared__ uint32_t s_cnt[RL];                     // histogram, then staging cursors
     __shared__ uint32_t s_delta[SCATTER ? RL : 1];     // (global bucket position - position in the stage) per partition
     __shared__ uint32_t s_stage[SCATTER ? PART_STAGE : 1];
     __shared__ uint32_t s_stage_tw[(SCATTER && TW) ? PART_STAGE : 1];
     __shared__ uint32_t s_full;                        // a capacity-sized bucket of this chunk's aid is full
-    __shared__ uint32_t s_n;                           // records staged so far
     __shared__ uint8_t s_seg[NW * 256 + 32];           // gather: segment -> descriptor lane, per wave (+ pad: for_each_record_seg reads past a wave's last segment)
     const int wid = threadIdx.x >> 6;
-    for (uint32_t ci = blockIdx.x; ci < a.n_chunks; ci += gridDim.x) {
-        const uint64_t ch = a.chunks[ci];
-        const uint32_t x = (uint32_t)(ch & REC_AID_MASK);
+    const unsigned lane = lane_id();
+    struct Chunk {                                     // everything a chunk needs before its records (uniform)
+        uint32_t x; int lgR, pshift; uint64_t g0, rb, re; bool direct;
+    };
+    auto derive = [&](uint64_t ch, uint64_t c64, uint32_t boost, uint64_t rs0, uint64_t rs1, uint64_t g0) {
+        Chunk k;
+        k.x = (uint32_t)(ch & REC_AID_MASK);
         const uint64_t c = ch >> 26;
-        const int lgR = l_log2r(a.cnt64[x], a.boost[x], a.l_cap, a.allow_packed);
-        const uint32_t R = 1u << lgR, pmask = R - 1u;
-        const int pshift = 32 - heavy_log2t(a.cnt64[x], a.allow_packed, a.l_cap) - lgR;
-        const uint64_t g0 = a.litem_start[x];
-        const uint64_t x_base = SCATTER ? a.pstart[g0] : 0ull;
-        const uint64_t rb = a.run_start[x] + c * PART_CHUNK_RUNS;
-        uint64_t re = rb + PART_CHUNK_RUNS;
-        if (re > a.run_start[x + 1]) re = a.run_start[x + 1];
-        const bool direct = lgR > (SCATTER ? PART_STAGE_LOG2R : PART_LDS_LOG2R) || (a.cnt64[x] & CNT_REC_MASK) >= (1ull << 31) ||
-                            (SCATTER && a.window_max * PART_CHUNK_RUNS > PART_STAGE);
-        if (direct) {
-            // no LDS staging (giant aids, or the time channel travels along): global cursor per record
-            for_each_record<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t slot) {
-                const uint64_t g = g0 + ((rec_hash(rc) >> pshift) & pmask);
-                if (!SCATTER) atomicAdd(&a.pcount[g], 1u);
-                else {
-                    const uint64_t pos = a.pstart[g] + atomicAdd(&a.pcursor[g], 1u);
-                    if (pos >= a.pstart[g + 1]) {                      // capacity-sized bucket is full
-                        if (atomicExch(&a.flag[x], 1u) == 0u) atomicAdd(a.ovf_count, 1u);
-                    } else {
-                        a.prec[pos] = rc;
-                        if (a.ptw) a.ptw[pos] = a.tw[slot];
-                    }
+        k.lgR = l_log2r(c64, (int)boost, a.l_cap, a.allow_packed);
+        k.pshift = 32 - heavy_log2t(c64, a.allow_packed, a.l_cap) - k.lgR;
+        k.g0 = g0;
+        k.rb = rs0 + c * PART_CHUNK_RUNS;
+        k.re = k.rb + PART_CHUNK_RUNS;
+        if (k.re > rs1) k.re = rs1;
+        k.direct = k.lgR > (SCATTER ? PART_STAGE_LOG2R : PART_LDS_LOG2R) || (c64 & CNT_REC_MASK) >= (1ull << 31) ||
+                   (SCATTER && a.window_max * PART_CHUNK_RUNS > PART_STAGE);
+        return k;
+    };
+    // no LDS staging (giant aids): global cursor per record
+    auto run_direct = [&](const Chunk& k) {
+        const uint32_t pmask = (1u << k.lgR) - 1u;
+        for_each_record<NW, 8>(a.sorted_desc, a.rec, k.rb, k.re, wid, [&](uint32_t rc, uint64_t slot) {
+            const uint64_t g = k.g0 + ((rec_hash(rc) >> k.pshift) & pmask);
+            if (!SCATTER) atomicAdd(&a.pcount[g], 1u);
+            else {
+                const uint64_t pos = a.pstart[g] + atomicAdd(&a.pcursor[g], 1u);
+                if (pos >= a.pstart[g + 1]) {                      // capacity-sized bucket is full
+                    if (atomicExch(&a.flag[k.x], 1u) == 0u) atomicAdd(a.ovf_count, 1u);
+                } else {
+                    a.prec[pos] = rc;
+                    if (a.ptw) a.ptw[pos] = a.tw[slot];
                 }
+            }
+        });
+    };
+    if constexpr (!SCATTER) {
+        // count pass (retry rounds only): histogram per chunk in LDS, one global add per (chunk, partition)
+        for (uint32_t ci = blockIdx.x; ci < a.n_chunks; ci += gridDim.x) {
+            const uint64_t ch = a.chunks[ci];
+            const uint32_t x = (uint32_t)(ch & REC_AID_MASK);
+            const Chunk k = derive(ch, a.cnt64[x], a.boost[x], a.run_start[x], a.run_start[x + 1], a.litem_start[x]);
+            if (k.direct) { run_direct(k); continue; }
+            const uint32_t R = 1u << k.lgR, pmask = R - 1u;
+            for (uint32_t p = threadIdx.x; p < R; p += 256) s_cnt[p] = 0;
+            __syncthreads();
+            for_each_record<NW, 8>(a.sorted_desc, a.rec, k.rb, k.re, wid, [&](uint32_t rc, uint64_t) {
+                atomicAdd(&s_cnt[(rec_hash(rc) >> k.pshift) & pmask], 1u);
             });
-            continue;
+            __syncthreads();
+            for (uint32_t p = threadIdx.x; p < R; p += 256) {
+                const uint32_t n = s_cnt[p];
+                if (n) atomicAdd(&a.pcount[k.g0 + p], n);
+            }
+            __syncthreads();
         }
-        for (uint32_t p = threadIdx.x; p < R; p += 256) s_cnt[p] = 0;
-        if (threadIdx.x == 0) { s_full = 0; s_n = 0; }
-        __syncthreads();
-        if (!SCATTER) {
-            for_each_record<NW, 8>(a.sorted_desc, a.rec, rb, re, wid, [&](uint32_t rc, uint64_t) {
-                atomicAdd(&s_cnt[(rec_hash(rc) >> pshift) & pmask], 1u);
-            });
-            __syncthreads();
-            for (uint32_t p = threadIdx.x; p < R; p += 256) {
-                const uint32_t n = s_cnt[p];
-                if (n) atomicAdd(&a.pcount[g0 + p], n);
+    } else {
+        uint32_t vz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(vz));     // opaque zero: keeps the prefetches below on the vector memory path
+        auto uni64 = [&](uint64_t v) -> uint64_t {
+            return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        };
+        constexpr uint64_t NO_CHUNK = ~0ull;
+        auto ld_chunk = [&](uint64_t ci) -> uint64_t { return ci < a.n_chunks ? a.chunks[ci + vz] : NO_CHUNK; };
+        struct Aid { uint64_t c64, rs0, rs1, g0; uint32_t boost; };
+        auto ld_aid = [&](uint64_t ch) {                // ch uniform
+            Aid m{0, 0, 0, 0, 0};
+            if (ch != NO_CHUNK) {
+                const uint32_t x = (uint32_t)(ch & REC_AID_MASK) + vz;
+                m.c64 = a.cnt64[x]; m.boost = a.boost[x]; m.rs0 = a.run_start[x]; m.rs1 = a.run_start[x + 1]; m.g0 = a.litem_start[x];
             }
-        } else {
-            // ONE pass over the chunk's records: they land in the LDS stage in arrival order (wave-aggregated cursor)
-            // while the per-partition histogram is taken; the scatter then reads them back from LDS
-            const unsigned lane = lane_id();
-            for_each_record_seg<NW, 4, TW>(a.sorted_desc, a.rec, rb, re, wid, s_seg + wid * 256, [&](uint32_t (&rc)[4], uint64_t (&sl)[TW ? 4 : 1], uint64_t (&ok)[4]) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint64_t m = ok[u];
-                    if (m == 0) continue;
-                    const int leader = __ffsll((unsigned long long)m) - 1;
-                    uint32_t base = 0;
-                    if ((int)lane == leader) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
-                    base = (uint32_t)__shfl((int)base, leader, 64);
-                    if (__builtin_amdgcn_inverse_ballot_w64(m)) {
-                        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                        s_stage[SCATTER ? pos : 0] = rc[u];
-                        if (TW) s_stage_tw[(SCATTER && TW) ? pos : 0] = a.tw[sl[TW ? u : 0]];
-                        atomicAdd(&s_cnt[(rec_hash(rc[u]) >> pshift) & pmask], 1u);
-                    }
+            return m;
+        };
+        auto mk = [&](uint64_t ch, const Aid& m) { return derive(ch, uni64(m.c64), (uint32_t)__builtin_amdgcn_readfirstlane((int)m.boost), uni64(m.rs0), uni64(m.rs1), uni64(m.g0)); };
+        auto ld_desc = [&](const Chunk& k) -> uint64_t {
+            const uint64_t mine = k.rb + (uint64_t)lane * NW + wid;
+            return mine < k.re ? a.sorted_desc[mine] : 0ull;
+        };
+        const uint64_t G = gridDim.x;
+        uint64_t ci = blockIdx.x;
+        if (ci >= a.n_chunks) return;
+        uint64_t ch_cur = uni64(ld_chunk(ci));
+        uint64_t ch_nxt_v = ld_chunk(ci + G);
+        Chunk cur = mk(ch_cur, ld_aid(ch_cur));
+        uint64_t xb_cur_v = a.pstart[cur.g0 + vz];
+        uint64_t d_cur = ld_desc(cur);
+        for (; ci < a.n_chunks; ci += G) {
+            const uint64_t ch_nxt = uni64(ch_nxt_v);     // requested one chunk ago
+            const uint64_t ch_n2_v = ld_chunk(ci + 2 * G);
+            const Aid aid_nxt = ld_aid(ch_nxt);          // lands while this chunk's records are gathered
+            Chunk nxt{};
+            uint64_t xb_nxt_v = 0, d_nxt = 0;
+            const uint32_t x = cur.x;
+            const uint32_t R = 1u << cur.lgR, pmask = R - 1u;
+            const int pshift = cur.pshift;
+            const uint64_t g0 = cur.g0;
+            auto stage3 = [&]() {                        // bucket base + run descriptors of the next chunk
+                if (ch_nxt != NO_CHUNK) {
+                    nxt = mk(ch_nxt, aid_nxt);
+                    xb_nxt_v = a.pstart[nxt.g0 + vz];
+                    d_nxt = ld_desc(nxt);
                 }
-            });
-            __syncthreads();
-            const uint32_t total = s_n;
-            // one global cursor bump per (chunk, partition) reserves the chunk's piece of every bucket
-            for (uint32_t p = threadIdx.x; p < R; p += 256) {
-                const uint32_t n = s_cnt[p];
-                uint32_t gpos = 0;
-                if (n) {
-                    const uint32_t old = atomicAdd(&a.pcursor[g0 + p], n);
-                    gpos = (uint32_t)(a.pstart[g0 + p] - x_base) + old;
-                    if ((uint64_t)old + n > a.pstart[g0 + p + 1] - a.pstart[g0 + p]) s_full = 1u;   // full: nothing of this chunk is written
-                }
-                s_delta[SCATTER ? p : 0] = gpos;
-                s_cnt[p] = 0;
-            }
-            __syncthreads();
-            if (s_full) {                                              // block-uniform
-                if (threadIdx.x == 0 && atomicExch(&a.flag[x], 1u) == 0u) atomicAdd(a.ovf_count, 1u);
+            };
+            if (cur.direct) {
+                run_direct(cur);
+                stage3();
+            } else {
+                for (uint32_t p = threadIdx.x; p < R; p += 256) s_cnt[p] = 0;
+                if (threadIdx.x == 0) s_full = 0;
                 __syncthreads();
-                continue;
+                // ONE pass over the chunk's records: each wave appends its records to its own region of the LDS stage
+                // (wave-private cursor: no atomics) while the per-partition histogram is taken
+                uint32_t wn = 0;
+                for_each_record_seg<NW, 4, TW>(a.sorted_desc, a.rec, cur.rb, cur.re, wid, s_seg + wid * 256, [&](uint32_t (&rc)[4], uint64_t (&sl)[TW ? 4 : 1], uint64_t (&ok)[4]) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint64_t m = ok[u];
+                        if (m == 0) continue;
+                        if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+                            const uint32_t pos = (uint32_t)wid * WSTAGE + wn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            s_stage[SCATTER ? pos : 0] = rc[u];
+                            if (TW) s_stage_tw[(SCATTER && TW) ? pos : 0] = a.tw[sl[TW ? u : 0]];
+                            atomicAdd(&s_cnt[(rec_hash(rc[u]) >> pshift) & pmask], 1u);
+                        }
+                        wn += (uint32_t)__popcll(m);
+                    }
+                }, &d_cur);
+                __syncthreads();
+                stage3();
+                const uint64_t x_base = uni64(xb_cur_v);
+                // one global cursor bump per (chunk, partition) reserves the chunk's piece of every bucket
+                for (uint32_t p = threadIdx.x; p < R; p += 256) {
+                    const uint32_t n = s_cnt[p];
+                    uint32_t gpos = 0;
+                    if (n) {
+                        const uint32_t old = atomicAdd(&a.pcursor[g0 + p], n);
+                        gpos = (uint32_t)(a.pstart[g0 + p] - x_base) + old;
+                        if ((uint64_t)old + n > a.pstart[g0 + p + 1] - a.pstart[g0 + p]) s_full = 1u;   // full: nothing of this chunk is written
+                    }
+                    s_delta[SCATTER ? p : 0] = gpos;
+                    s_cnt[p] = 0;
+                }
+                __syncthreads();
+                if (s_full) {                                              // block-uniform
+                    if (threadIdx.x == 0 && atomicExch(&a.flag[x], 1u) == 0u) atomicAdd(a.ovf_count, 1u);
+                } else {
+                    // a partition's records of this chunk go to one contiguous piece of its bucket (order inside is free)
+                    for (uint32_t i = lane; i < wn; i += 64) {
+                        const uint32_t si = (uint32_t)wid * WSTAGE + i;
+                        const uint32_t rc = s_stage[SCATTER ? si : 0];
+                        const uint32_t p = (rec_hash(rc) >> pshift) & pmask;
+                        const uint64_t o = x_base + (uint64_t)(s_delta[SCATTER ? p : 0] + atomicAdd(&s_cnt[p], 1u));
+                        a.prec[o] = rc;
+                        if (TW) a.ptw[o] = s_stage_tw[(SCATTER && TW) ? si : 0];
+                    }
+                }
+                __syncthreads();
             }
-            // a partition's records of this chunk go to one contiguous piece of its bucket (order inside is free)
-            for (uint32_t i = threadIdx.x; i < total; i += 256) {
-                const uint32_t rc = s_stage[SCATTER ? i : 0];
-                const uint32_t p = (rec_hash(rc) >> pshift) & pmask;
-                const uint64_t o = x_base + (uint64_t)(s_delta[SCATTER ? p : 0] + atomicAdd(&s_cnt[p], 1u));
-                a.prec[o] = rc;
-                if (TW) a.ptw[o] = s_stage_tw[(SCATTER && TW) ? i : 0];
-            }
+            cur = nxt;
+            xb_cur_v = xb_nxt_v;
+            d_cur = d_nxt;
+            ch_nxt_v = ch_n2_v;
         }
-        __syncthreads();
     }
 }
 
@@ -3299,6 +3375,7 @@ struct otto_covis_ctx {
     DevBuf bcount, bstart, tmp_runs;          // bucketed index
     int bucket_index = 1;          // option "bucket_index": LDS-atomic index build (0 = global-atomic histogram)
     int s_wgs = 20;                // option "s_wgs": one-wave workgroups of the S bin per CU (A/B)
+    int p_wgs = 4;                 // option "p_wgs": workgroups of the partition scatter per CU (4 are resident: 38 KB of LDS each)
     int bkt_sh = 0;                // option "bkt_sh": log2 aids per index bucket (0 = from the aid space)
     DevBuf lorder[3][3], lrank, lmode_start;   // [bin][mode] processing order of the tiers / layouts (heavy: pilots first)
     uint64_t n_order[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -3778,7 +3855,8 @@ static int run_partition(otto_covis_ctx* c, const ReduceArgs& a, bool time, hipS
                 c->litem_start.as<uint64_t>(), c->pcount.as<uint32_t>(), c->pcursor.as<uint32_t>(),
                 c->pstart.as<uint64_t>(), nullptr, nullptr, c->l_cap, c->p.window, a.allow_packed, c->flag.as<uint32_t>(),
                 c->counters.as<uint32_t>()};
-    const uint32_t pgrid = (uint32_t)(c->n_chunks < 256u * 5u ? c->n_chunks : 256u * 5u);
+    const uint32_t pres = 256u * (uint32_t)c->p_wgs;
+    const uint32_t pgrid = (uint32_t)(c->n_chunks < pres ? c->n_chunks : pres);   // chunks are dealt statically
     const uint32_t cgrid = (uint32_t)(c->n_chunks < 256u * 8u ? c->n_chunks : 256u * 8u);
     // First attempt: buckets sized from the record counts the index already holds (2 x mean + margin), no count pass.
     // Retry rounds (aids whose bucket or LDS table overflowed): counted buckets, exact.
@@ -4045,6 +4123,7 @@ extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_
     if (strcmp(name, "bucket_index") == 0) { c->bucket_index = value != 0; return 0; }
     if (strcmp(name, "guess") == 0) { c->guess = value != 0; return 0; }           // threshold guessing on/off (A/B)
     if (strcmp(name, "fused") == 0) { c->fused = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return 0; }   // 2 component lists, 1 fused register rows, 0 class-sorted kernels (A/B)
+    if (strcmp(name, "p_wgs") == 0) { c->p_wgs = value < 1 ? 1 : (value > 128 ? 128 : (int)value); return 0; }
     if (strcmp(name, "s_wgs") == 0) { c->s_wgs = value < 1 ? 1 : (value > 32 ? 32 : (int)value); return 0; }
     if (strcmp(name, "bkt_sh") == 0) { c->bkt_sh = (int)value; c->index_valid = false; return 0; }
     if (strcmp(name, "overlap_partition") == 0) { c->overlap_partition = value != 0; return 0; }
