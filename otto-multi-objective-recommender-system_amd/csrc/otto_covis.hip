@@ -3375,7 +3375,8 @@ struct otto_covis_ctx {
     DevBuf bcount, bstart, tmp_runs;          // bucketed index
     int bucket_index = 1;          // option "bucket_index": LDS-atomic index build (0 = global-atomic histogram)
     int s_wgs = 20;                // option "s_wgs": one-wave workgroups of the S bin per CU (A/B)
-    int p_wgs = 4;                 // option "p_wgs": workgroups of the partition scatter per CU (4 are resident: 38 KB of LDS each)
+    int p_wgs = 12;                // option "p_wgs": workgroups of the partition scatter per CU. 4 are resident (38 KB of LDS each); chunks are dealt
+                                   // statically, so 3 rounds of workgroups even out the chunk sizes (sweep 3 .. 64 in profiles/round3/partition_pipeline_ab.log)
     int bkt_sh = 0;                // option "bkt_sh": log2 aids per index bucket (0 = from the aid space)
     DevBuf lorder[3][3], lrank, lmode_start;   // [bin][mode] processing order of the tiers / layouts (heavy: pilots first)
     uint64_t n_order[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
