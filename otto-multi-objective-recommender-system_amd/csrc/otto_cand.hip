@@ -38,6 +38,7 @@ struct CandArgs {
     int32_t* self_count;           // nullable: [n_events] Counter count of every event's aid; the session's aids then leave the selection
 #ifdef OTTO_PHASE_PROF
     unsigned long long* prof;      // [8] shader-clock ticks of thread 0 per phase (diagnostic build)
+    int debug;                     // diagnostic build, env OTTO_CAND_DEBUG (wrong results): 1 no inserts, 2 no list loads, 4 no selection
 #endif
 };
 #ifdef OTTO_PHASE_PROF
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
     __shared__ uint32_t s_fp[CD_T];                    // first position
     __shared__ uint64_t s_sel[OTTO_CAND_MAX_COMMON];   // running most_common list (sorted)
     __shared__ uint64_t s_lb[CD_THREADS];
-    __shared__ uint64_t s_ex[CD_EXCAP];
+    __shared__ uint64_t s_ex[OTTO_CAND_MAX_COMMON];
     __shared__ uint64_t s_thr;
     __shared__ uint32_t s_nex, s_more, s_ovf, s_nfresh, s_sp, s_scan[CD_NW + 1], s_keep[2], s_maxlen;
     __shared__ uint32_t s_stack[CD_STACK];            // hash partitions still to do: id | level << 24
@@ -250,6 +251,10 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                                 for (int v = 1; v < OTTO_CAND_MAX_TERMS; ++v) t += (q >= tstart[v]) ? 1 : 0;
                                 const uint32_t x = src_aid(a.p.term_source[t], q - tstart[t]);
                                 const int m = a.p.term_matrix[t];
+#ifdef OTTO_PHASE_PROF
+                                if (a.debug & 2) yv[u] = (x * 2654435761u + l2 * 40503u) % a.p.n_aids;
+                                else
+#endif
                                 yv[u] = (uint32_t)a.p.d_mat_y[m][(size_t)x * (a.p.mat_k[m] > 0 ? a.p.mat_k[m] : K) + l2];
                                 pv[u] = (b & 0xFFFFFFu) + l2;
                                 ok[u] = true;
@@ -260,6 +265,9 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
 #pragma unroll
                     for (int u = 0; u < GU; ++u) {
                         bool fr = false;
+#ifdef OTTO_PHASE_PROF
+                        if ((a.debug & 1) && ok[u]) { if (yv[u] == 0xDEADBEEFu) s_ovf = 1; ok[u] = false; }
+#endif
                         if (ok[u]) {
                         const uint32_t y = yv[u];
                         const uint32_t h = y * 0x9E3779B1u;
@@ -335,94 +343,100 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                 }
                 __syncthreads();
             }
-            // candidates of this lane: its table slots and (carried over from earlier partitions) two entries of s_sel
-            auto cand_of = [&](int q) -> KeyN {
-                KeyN k;
-                k.c = 0;
-                if (q < mpl) {
-                    const int i = q * CD_THREADS + tid;
-                    const unsigned long long v = s_tab[i];
-                    if (v != CD_EMPTY && (v & 0xFFFFFFFFull) != 0) k.c = cand_key(v & 0xFFFFFFFFull, s_fp[i], (uint32_t)(v >> 32));
-                } else {
-                    const int i = tid + (q - mpl) * CD_THREADS;
-                    if (have_sel && i < NC) k.c = s_sel[i];
-                }
-                return k;
-            };
-            const int NCAND = mpl + 1;                           // NC <= 128 <= CD_THREADS: one carried entry per thread
-            uint64_t selA = 0, selB = 0;                          // lane i of wave 0: i-th / (64+i)-th most common
-            uint64_t limit = ~0ull;                               // round 2 only takes keys below the 64th of round 1
-            for (int round = 0; round < 2; ++round) {
-                const int kk = round == 0 ? (NC < 64 ? NC : 64) : NC - 64;
-                if (kk <= 0) break;
-                KeyN lb;
-                lb.c = 0;
-                uint32_t done = 0;
-                int bi = -1;
-#pragma unroll 2
-                for (int q = 0; q < NCAND; ++q) {
-                    const KeyN c = cand_of(q);
-                    if (c.c < limit && kbetter(c, lb)) { lb = c; bi = q; }
-                }
-                if (bi >= 0) done |= 1u << bi;
-                s_lb[tid] = lb.c;
-                if (tid == 0) { s_nex = 0; s_more = 0; }
-                __syncthreads();
-                KeyN best;
-                best.c = 0;
-                if (wid == 0) {
-                    KeyN lbs[CD_NW];
+            // ---- most_common(NC) of this partition's table + the list carried over from the earlier partitions ----
+            // Order: count descending, first position ascending (first positions are distinct: one aid per position of the
+            // concatenation), i.e. the ORDER KEY  count << TB | (2^TB - 1 - first position)  with TB = bits of TOT. The
+            // NC-th largest order key is found exactly by a most-significant-digit radix select (8-bit digits, 2 - 3 passes
+            // for count < 2^8 and TOT < 2^13): every thread keeps its <= 9 candidates in registers, a pass is one LDS histogram
+            // of the candidates that match the digits fixed so far + one 256-bin scan by wave 0. Then the selected keys (exactly
+            // NC of them, or every candidate) are compacted and ranked by counting. All waves work in every step; the former
+            // path (lane bests -> 64-lane sort -> one-by-one pushes into a sorted list held by wave 0, two rounds of 64) cost
+            // several thousand instructions on a single wave per partition.
+            {
+                constexpr int MAXC = CD_T / CD_THREADS + 1;          // table slots per thread + one carried entry
+                const int TB = 32 - __clz((int)(TOT | 1u));             // first positions < TOT <= 2^TB
+                const uint64_t fpb = 0xFFFFFFull - ((1ull << TB) - 1ull);
+                uint64_t ck[MAXC], ok[MAXC];
 #pragma unroll
-                    for (int q = 0; q < CD_NW; ++q) lbs[q].c = s_lb[q * 64 + lane];
-                    wave_topk_select<CD_NW, KeyN>(lbs, kk, best);
-                    const KeyN thr = kshfl(best, kk - 1);
-                    if (lane == 0) s_thr = thr.c;
+                for (int q = 0; q < MAXC; ++q) {
+                    uint64_t c = 0;
+                    if (q < mpl) {
+                        const int i = q * CD_THREADS + tid;
+                        const unsigned long long v = s_tab[i];
+                        if (v != CD_EMPTY && (v & 0xFFFFFFFFull) != 0) c = cand_key(v & 0xFFFFFFFFull, s_fp[i], (uint32_t)(v >> 32));
+                    } else if (q == mpl) {
+                        if (have_sel && tid < NC) c = s_sel[tid];
+                    }
+                    ck[q] = c;
+                    ok[q] = c ? (((c >> 50) << TB) | (((c >> 26) & 0xFFFFFFull) - fpb)) : 0ull;
                 }
-                for (;;) {
+                uint32_t* hist = reinterpret_cast<uint32_t*>(s_lb);   // 256 bins (s_lb: CD_THREADS x 8 bytes >= 1 KB)
+                for (int i = tid; i < 256; i += CD_THREADS) hist[i] = 0;
+                if (tid == 0) { s_nex = 0; s_thr = 0; }
+                // a key occurs at most once per list: count <= Q
+                const int W = TB + (32 - __clz((int)(Q | 1u)));
+                const int P = (W + 7) >> 3;
+                uint64_t prefix = 0;                                  // the digits fixed so far (order key >> (shift + 8))
+                uint32_t need = (uint32_t)NC;
+                bool all = false;                                     // fewer candidates than NC: every candidate is selected
+                __syncthreads();
+                for (int pass = 0; pass < P; ++pass) {
+                    const int shift = 8 * (P - 1 - pass);
+#pragma unroll
+                    for (int q = 0; q < MAXC; ++q) {
+                        const bool in = ok[q] != 0 && (ok[q] >> (shift + 8)) == prefix;
+                        const uint32_t d = (uint32_t)(ok[q] >> shift) & 255u;
+                        // most candidates of a wave share the digit (small counts): one add for all of them
+                        const uint64_t m_in = __ballot(in);
+                        if (m_in == 0) continue;
+                        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, __builtin_ctzll(m_in));
+                        const uint64_t m0 = __ballot(in && d == d0);
+                        if (lane == (unsigned)__builtin_ctzll(m_in)) atomicAdd(&hist[d0], (uint32_t)__popcll(m0));
+                        if (in && d != d0) atomicAdd(&hist[d], 1u);
+                    }
                     __syncthreads();
-                    const uint64_t thr = s_thr;
-#pragma unroll 2
-                    for (int q = 0; q < NCAND; ++q) {
-                        if ((done >> q) & 1u) continue;
-                        const KeyN c = cand_of(q);
-                        if (c.c != 0 && c.c < limit && c.c > thr) {
-                            const uint32_t pos = atomicAdd(&s_nex, 1u);
-                            if (pos < (uint32_t)CD_EXCAP) { s_ex[pos] = c.c; done |= 1u << q; }
-                            else s_more = 1;
+                    if (wid == 0) {
+                        const uint4 h = reinterpret_cast<const uint4*>(hist)[lane];            // bins 4 lane .. 4 lane + 3
+                        reinterpret_cast<uint4*>(hist)[lane] = make_uint4(0u, 0u, 0u, 0u);      // cleared for the next pass
+                        const uint32_t sum = h.x + h.y + h.z + h.w;
+                        const uint32_t incl = wave_incl_scan(sum);
+                        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        const uint32_t a3 = total - incl, a2 = a3 + h.w, a1 = a2 + h.z, a0 = a1 + h.y;    // candidates in the bins above bin 3, 2, 1, 0 of this lane
+                        if (pass == 0 && total < need) {
+                            if (lane == 0) s_more = 0xFFFFFFFFu;       // take every candidate
+                        } else {
+                            int b = -1;
+                            uint32_t above = 0;
+                            if (a3 < need && need <= a3 + h.w) { b = 3; above = a3; }
+                            else if (a2 < need && need <= a2 + h.z) { b = 2; above = a2; }
+                            else if (a1 < need && need <= a1 + h.y) { b = 1; above = a1; }
+                            else if (a0 < need && need <= a0 + h.x) { b = 0; above = a0; }
+                            if (b >= 0) { s_more = 4u * lane + (uint32_t)b; s_keep[0] = need - above; }
                         }
                     }
                     __syncthreads();
-                    const bool more = s_more != 0;
-                    if (wid == 0) {
-                        const uint32_t ne = s_nex < (uint32_t)CD_EXCAP ? s_nex : (uint32_t)CD_EXCAP;
-                        KeyN cnd;
-                        cnd.c = lane < ne ? s_ex[lane] : 0ull;
-                        wave_topk_push(best, cnd, kk);
-                        const KeyN t2 = kshfl(best, kk - 1);
-                        if (more && lane == 0) s_thr = t2.c;
-                    }
-                    if (!more) break;
-                    __syncthreads();
-                    if (tid == 0) { s_nex = 0; s_more = 0; }
+                    const uint32_t dsel = s_more;
+                    if (dsel == 0xFFFFFFFFu) { all = true; break; }
+                    prefix = (prefix << 8) | dsel;
+                    need = s_keep[0];
                 }
-                if (wid == 0) {
-                    if (round == 0) selA = (int)lane < kk ? best.c : 0ull;
-                    else selB = (int)lane < kk ? best.c : 0ull;
-                    const uint64_t lim = kshfl(best, kk - 1).c;
-                    if (lane == 0) s_thr = lim;
-                }
+                const uint64_t thr = all ? 0ull : prefix;              // the NC-th largest order key (the last pass fixes its last digit)
+#pragma unroll
+                for (int q = 0; q < MAXC; ++q)
+                    if (ok[q] != 0 && ok[q] >= thr) s_ex[atomicAdd(&s_nex, 1u)] = ck[q];
                 __syncthreads();
-                limit = s_thr;                 // 64th key of round 1 (0 if fewer than 64 candidates -> round 2 finds nothing)
-                if (limit == 0) break;
+                const uint32_t nsel = s_nex;                           // <= NC: order keys are distinct
+                if (tid < NC) {
+                    if ((uint32_t)tid < nsel) {
+                        const uint64_t key = s_ex[tid];
+                        uint32_t rank = 0;
+                        for (uint32_t i = 0; i < nsel; ++i) rank += s_ex[i] > key ? 1u : 0u;
+                        s_sel[rank] = key;
+                    } else s_sel[tid] = 0;
+                }
+                have_sel = true;
                 __syncthreads();
             }
-            __syncthreads();
-            if (wid == 0) {
-                s_sel[lane] = selA;
-                if (64 + (int)lane < NC) s_sel[64 + lane] = selB;
-            }
-            have_sel = true;
-            __syncthreads();
             CD_PH(5);
         }
         __syncthreads();
@@ -839,6 +853,7 @@ static int cand_lookup(const otto_cand_params* p, const uint32_t* d_aid, const u
     if (!d_prof) { OTTO_HIP(hipMalloc(&d_prof, 128)); for (auto& e : pe) OTTO_HIP(hipEventCreate(&e)); }
     OTTO_HIP(hipMemsetAsync(d_prof, 0, 128, s));
     a.prof = d_prof;
+    a.debug = getenv("OTTO_CAND_DEBUG") ? atoi(getenv("OTTO_CAND_DEBUG")) : 0;
     (void)hipEventRecord(pe[0], s);
 #endif
     // short sessions first (most of them), then the long ones; each variant skips the other's sessions
