@@ -91,6 +91,12 @@ inline int device_scratch(int slot, size_t bytes, void** out, hipStream_t s) {
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 
+// LDS traffic between the lanes of ONE wave: the LDS queue of a wave is in order, so only the compiler needs a fence
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_incl_scan(T v) {
     const unsigned l = lane_id();
@@ -99,6 +105,18 @@ __device__ __forceinline__ T wave_incl_scan(T v) {
         T o = __shfl_up(v, d, 64);
         if (l >= (unsigned)d) v += o;
     }
+    return v;
+}
+// 32-bit values: six DPP adds (row_shr 1 / 2 / 4 / 8 inside the 16-lane rows, then row_bcast:15 into rows 1 and 3 and
+// row_bcast:31 into rows 2 and 3) instead of six dependent ds_bpermute round trips through the LDS crossbar
+template <>
+__device__ __forceinline__ uint32_t wave_incl_scan<uint32_t>(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
     return v;
 }
 

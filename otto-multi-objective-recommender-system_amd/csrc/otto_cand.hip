@@ -34,7 +34,9 @@ struct CandArgs {
     int32_t* count;
     int32_t* n_out;
     uint32_t* err;
-    int lo_len, hi_len;            // this launch handles sessions with lo_len <= events <= hi_len
+    const uint32_t* list;          // this launch's sessions (k_cand_classify: the short ones / the long ones)
+    const uint32_t* list_n;        // their number
+    uint32_t* work;                // dequeue counter: sessions cost from a few to a few hundred microseconds, a static split leaves a tail
     int32_t* self_count;           // nullable: [n_events] Counter count of every event's aid; the session's aids then leave the selection
 #ifdef OTTO_PHASE_PROF
     unsigned long long* prof;      // [8] shader-clock ticks of thread 0 per phase (diagnostic build)
@@ -51,6 +53,27 @@ __device__ __forceinline__ uint64_t cand_key(uint64_t count, uint32_t fp, uint32
     return (count << 50) | ((uint64_t)(0xFFFFFFu - fp) << 26) | (uint64_t)y;
 }
 
+// Sessions by length class: hdr[0] / hdr[1] = number of short (<= CD_SMALL_MAXL events) / long sessions, their ids in lists[0] / lists[1]
+// (n_sess entries each). One returning atomic per wave and class.
+__global__ __launch_bounds__(256) void k_cand_classify(const int64_t* sess_off, int64_t n_sess, uint32_t* hdr, uint32_t* list_short, uint32_t* list_long) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned lane = lane_id();
+    const bool in = s < n_sess;
+    const int64_t n = in ? sess_off[s + 1] - sess_off[s] : 0;
+    const bool is_long = in && n > CD_SMALL_MAXL;
+    const uint64_t ml = __ballot(is_long), ms = __ballot(in && !is_long);
+    uint32_t bl = 0, bs = 0;
+    if (lane == 0) {
+        if (ml) bl = atomicAdd(&hdr[1], (uint32_t)__popcll(ml));
+        if (ms) bs = atomicAdd(&hdr[0], (uint32_t)__popcll(ms));
+    }
+    bl = (uint32_t)__builtin_amdgcn_readfirstlane((int)bl);
+    bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)bs);
+    const uint64_t below = (1ull << lane) - 1ull;
+    if (is_long) list_long[bl + (uint32_t)__popcll(ml & below)] = (uint32_t)s;
+    else if (in) list_short[bs + (uint32_t)__popcll(ms & below)] = (uint32_t)s;
+}
+
 // Two instantiations share the code: <32, 10, 128> for short sessions (16 KB of LDS: ten workgroups per CU instead of
 // two -- most sessions are short and the per-session phases are barrier / latency bound) and <500, 12, 256> for the rest.
 template <int CD_MAXL, int CD_LOG2T, int CD_THREADS>
@@ -60,9 +83,9 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
     constexpr int CD_CAP = CD_T / 4 * 3;                 // list entries per hash partition (load <= 3/4)
     constexpr int CD_MAXQ = OTTO_CAND_MAX_TERMS * CD_MAXL;
     static_assert(CD_THREADS >= OTTO_CAND_MAX_COMMON && CD_NW >= 2, "one carried entry per thread, two compaction waves");
-    __shared__ uint32_t s_aid[CD_MAXL];
-    __shared__ uint8_t s_ty[CD_MAXL];
-    __shared__ uint8_t s_flag[CD_MAXL];               // bit0 last occurrence, bit1 first click/cart, bit2 first cart/order, bit3 first click
+    __shared__ __attribute__((aligned(16))) uint32_t s_aid[CD_MAXL];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ty[CD_MAXL];
+    __shared__ __attribute__((aligned(16))) uint8_t s_flag[CD_MAXL];   // bit0 last occurrence, bit1 first click/cart, bit2 first cart/order, bit3 first click
     __shared__ uint16_t s_src[4][CD_MAXL];            // U, CC, CO, C -- as EVENT positions; source LAST is the last event itself
                                                       // (the aid is s_aid[position]; 16-bit entries keep two of the long-session workgroups on a CU)
     __shared__ uint32_t s_nsrc[5];
@@ -75,6 +98,7 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
     __shared__ uint64_t s_thr;
     __shared__ uint32_t s_nex, s_more, s_ovf, s_nfresh, s_sp, s_scan[CD_NW + 1], s_keep[2], s_maxlen;
     __shared__ uint32_t s_stack[CD_STACK];            // hash partitions still to do: id | level << 24
+    __shared__ uint8_t s_seg[CD_NW * 256];            // gather: segment -> list lane << 2 | segment of the list, per wave
 
     const int tid = threadIdx.x, wid = tid >> 6;
     const unsigned lane = lane_id();
@@ -83,13 +107,22 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = clock64();
 #endif
 
-    for (int64_t s = blockIdx.x; s < a.n_sess; s += gridDim.x) {
+    __shared__ uint32_t s_next[2];
+    const uint32_t n_list = *a.list_n;
+    if (tid == 0) s_next[0] = atomicAdd(a.work, 1u);
+    __syncthreads();
+    uint32_t item = s_next[0];
+    for (uint32_t it = 0; item < n_list; ++it) {
+        // the next session is dequeued now: the counter's round trip is over long before this session is
+        if (tid == 0) s_next[(it + 1u) & 1u] = atomicAdd(a.work, 1u);
+        const int64_t s = (int64_t)a.list[item];
         const int64_t lo = a.sess_off[s], hi = a.sess_off[s + 1];
         const int n = (int)(hi - lo);
-        if (n < a.lo_len || n > a.hi_len) continue;        // the other variant's session
         CD_PH(0);
         if (n > CD_MAXL) {
             if (tid == 0) atomicAdd(a.err, 1u);
+            __syncthreads();
+            item = s_next[(it + 1u) & 1u];
             continue;
         }
         // ---- A ----------------------------------------------------------------------------------------
@@ -100,18 +133,32 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
             for (int i = tid; i < n; i += CD_THREADS) a.self_count[lo + i] = 0;
         for (int i = tid; i < NC; i += CD_THREADS) s_sel[i] = 0;
         __syncthreads();
+        // Flags and ranks compare every event with every other event of the session. The session is read FOUR events per LDS
+        // operation (one 16-byte read of aids, one 4-byte read of types / flags) and without branches: with two workgroups per
+        // CU and most waves of a workgroup waiting at the barrier, a loop of one dependent LDS read per event ran at one LDS round
+        // trip per event (a quarter of the long-session kernel).
         for (int i = tid; i < n; i += CD_THREADS) {
             const uint32_t ai = s_aid[i];
             const uint32_t ti = s_ty[i];
-            bool last = true, fcc = ti <= 1, fco = ti >= 1, fc = ti == 0;
-#pragma unroll 4
-            for (int j = 0; j < n; ++j) {
-                if (s_aid[j] != ai) continue;
-                if (j > i) last = false;
-                if (j < i && s_ty[j] <= 1) fcc = false;
-                if (j < i && s_ty[j] >= 1) fco = false;
-                if (j < i && s_ty[j] == 0) fc = false;
+            uint32_t later = 0, pcc = 0, pco = 0, pc = 0;        // same aid: later / earlier with type <= 1 / >= 1 / == 0
+#pragma unroll 2
+            for (int j0 = 0; j0 < n; j0 += 4) {
+                const uint4 a4 = *reinterpret_cast<const uint4*>(&s_aid[j0]);
+                const uint32_t t4 = *reinterpret_cast<const uint32_t*>(&s_ty[j0]);
+                const uint32_t aj[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = j0 + e;
+                    const uint32_t tj = (t4 >> (8 * e)) & 0xFFu;
+                    const uint32_t eq = (aj[e] == ai && j < n) ? 1u : 0u;
+                    const uint32_t before = eq & (j < i ? 1u : 0u);
+                    later |= eq & (j > i ? 1u : 0u);
+                    pcc |= before & (tj <= 1u ? 1u : 0u);
+                    pco |= before & (tj >= 1u ? 1u : 0u);
+                    pc |= before & (tj == 0u ? 1u : 0u);
+                }
             }
+            const bool last = later == 0, fcc = ti <= 1 && pcc == 0, fco = ti >= 1 && pco == 0, fc = ti == 0 && pc == 0;
             s_flag[i] = (uint8_t)((last ? 1 : 0) | (fcc ? 2 : 0) | (fco ? 4 : 0) | (fc ? 8 : 0));
         }
         __syncthreads();
@@ -122,13 +169,21 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                 const uint32_t ai = s_aid[i];
                 fl = s_flag[i];
                 uint32_t ru = 0, rcc = 0, rco = 0, rc = 0;
-#pragma unroll 4
-                for (int j = 0; j < n; ++j) {
-                    const uint32_t fj = s_flag[j], aj = s_aid[j];
-                    ru += (j > i) & (fj & 1u);
-                    rcc += ((fj >> 1) & 1u) & (aj < ai);
-                    rco += ((fj >> 2) & 1u) & (aj < ai);
-                    rc += ((fj >> 3) & 1u) & (aj < ai);
+#pragma unroll 2
+                for (int j0 = 0; j0 < n; j0 += 4) {
+                    const uint4 a4 = *reinterpret_cast<const uint4*>(&s_aid[j0]);
+                    const uint32_t f4 = *reinterpret_cast<const uint32_t*>(&s_flag[j0]);
+                    const uint32_t aj[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int j = j0 + e;
+                        const uint32_t fj = j < n ? (f4 >> (8 * e)) & 0xFFu : 0u;
+                        const uint32_t lt = aj[e] < ai ? 1u : 0u;
+                        ru += (j > i ? 1u : 0u) & (fj & 1u);
+                        rcc += ((fj >> 1) & 1u) & lt;
+                        rco += ((fj >> 2) & 1u) & lt;
+                        rc += ((fj >> 3) & 1u) & lt;
+                    }
                 }
                 if (fl & 1u) s_src[0][ru] = (uint16_t)i;
                 if (fl & 2u) s_src[1][rcc] = (uint16_t)i;
@@ -222,84 +277,112 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
             for (int i = tid; i < Teff; i += CD_THREADS) { s_tab[i] = CD_EMPTY; s_fp[i] = 0xFFFFFFFFu; }
             __syncthreads();
             CD_PH(3);
-            const int hw = tid >> 5, l = tid & 31;
-            // One half-wave per list, GU lists in flight per half-wave (the rows come from global memory; the inserts of a batch
-            // start when its rows have arrived). Round-3 measurements on the click recipe (111 - 118 ms run to run): rows in
-            // flight 1 -> 4, the per-wave distinct counter, double hashing and list sizes from ballots each left it unchanged --
-            // the gather + insert phase (47 - 56 % of the long-session kernel in the diagnostic build) is bound by none of the
-            // list loads, the same-address counter or the probe chains alone.
+            // Gather + insert. A wave takes 64 lists at a time, ONE LIST PER LANE for the set-up (position | length, source aid,
+            // row address: done once per list instead of once per list and 32-lane pass), cuts them into segments of 8 entries
+            // (wave scan of the segment counts, segment -> list lane in a byte table private to the wave) and deals the segments
+            // to its eight 8-lane groups: a wave-instruction carries up to 64 entries whatever the list lengths are (k = 15: 94 %
+            // of the lanes; one list per 32-lane half filled 47 %). The entry's lane fetches the list's words from the list's
+            // lane with three ds_bpermute. GU steps are in flight per lane; lists longer than 32 (neighbour lists) take a
+            // second sweep. (Round-3 measurements: a fifth of the long-session kernel was the loop skeleton alone -- set-up
+            // repeated per pass -- and a third the inserts, both per wave-instruction, not per entry.)
             constexpr int GU = 4;
-            constexpr uint32_t HWS = CD_THREADS / 32;
+            const uint32_t g8 = lane >> 3, gl = lane & 7u;
+            uint8_t* seg = s_seg + wid * 256;
             const uint32_t sweeps = s_maxlen > 32u ? (s_maxlen + 31u) / 32u : 1u;      // lists longer than 32 (neighbour lists): more sweeps
-            for (uint32_t sw = 0; sw < sweeps; ++sw) {
-                const uint32_t l2 = (uint32_t)l + 32u * sw;
-                for (uint32_t q0 = hw; q0 < Q; q0 += HWS * GU) {
-                    if (s_ovf) break;                             // the partition is being split: its table is not used
-                    uint32_t yv[GU], pv[GU];
-                    bool ok[GU];
+            for (uint32_t qb = 0; qb < Q; qb += (uint32_t)CD_NW * 64u) {            // lists dealt round-robin to the waves: short sessions keep every wave busy
+                if (s_ovf) break;                                 // the partition is being split: its table is not used
+                const uint32_t q = qb + lane * (uint32_t)CD_NW + (uint32_t)wid;
+                uint32_t b = 0;
+                uint64_t row = 0;
+                if (q < Q) {
+                    b = s_base[q];
 #pragma unroll
-                    for (int u = 0; u < GU; ++u) {
-                        const uint32_t q = q0 + (uint32_t)u * HWS;
-                        ok[u] = false;
-                        yv[u] = pv[u] = 0;
-                        if (q < Q) {
-                            const uint32_t b = s_base[q];
-                            const uint32_t len = b >> 24;
-                            if (l2 < len) {
-                                int t = 0;
+                    for (int t = 0; t < OTTO_CAND_MAX_TERMS; ++t) {
+                        if (t < a.p.n_terms && q >= tstart[t] && q < tstart[t + 1]) {          // t uniform: the term's words are scalars
+                            const int m = a.p.term_matrix[t];
+                            const uint32_t x = src_aid(a.p.term_source[t], q - tstart[t]);
+                            row = (uint64_t)(uintptr_t)a.p.d_mat_y[m] + ((uint64_t)x * (uint32_t)(a.p.mat_k[m] > 0 ? a.p.mat_k[m] : K)) * 4ull;
+                        }
+                    }
+                }
+                const int rlo = (int)(uint32_t)row, rhi = (int)(uint32_t)(row >> 32);
+                for (uint32_t sw = 0; sw < sweeps; ++sw) {
+                    const uint32_t len_all = b >> 24;
+                    const uint32_t len = len_all > 32u * sw ? (len_all - 32u * sw > 32u ? 32u : len_all - 32u * sw) : 0u;   // entries of this sweep
+                    const uint32_t segs = (len + 7u) >> 3;
+                    const uint32_t incl = wave_incl_scan(segs), excl = incl - segs;
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 #pragma unroll
-                                for (int v = 1; v < OTTO_CAND_MAX_TERMS; ++v) t += (q >= tstart[v]) ? 1 : 0;
-                                const uint32_t x = src_aid(a.p.term_source[t], q - tstart[t]);
-                                const int m = a.p.term_matrix[t];
+                    for (uint32_t k = 0; k < 4; ++k)
+                        if (k < segs) seg[excl + k] = (uint8_t)((lane << 2) | k);
+                    wave_lds_sync();
+                    const int blen = (int)((b & 0xFFFFFFu) + 32u * sw) | (int)(len << 24);       // position of the sweep's first entry | entries
+                    const int nstep = (int)((total + 7u) >> 3);
+                    for (int t0 = 0; t0 < nstep; t0 += GU) {
+                        uint32_t yv[GU], pv[GU];
+                        bool ok[GU];
+#pragma unroll
+                        for (int u = 0; u < GU; ++u) {
+                            const uint32_t sq = (uint32_t)(t0 + u) * 8u + g8;
+                            const uint32_t r = (uint32_t)seg[sq & 255u];
+                            const int src = (int)(r & 0xFCu);
+                            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, rlo);
+                            const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, rhi);
+                            const uint32_t bl = (uint32_t)__builtin_amdgcn_ds_bpermute(src, blen);
+                            const uint32_t off = ((r & 3u) << 3) | gl;                           // entry of the sweep
+                            ok[u] = sq < total && off < (bl >> 24);
+                            pv[u] = (bl & 0xFFFFFFu) + off;
+                            yv[u] = 0;
+                            if (ok[u]) {
 #ifdef OTTO_PHASE_PROF
-                                if (a.debug & 2) yv[u] = (x * 2654435761u + l2 * 40503u) % a.p.n_aids;
+                                if (a.debug & 2) yv[u] = (lo * 2654435761u + off * 40503u) % a.p.n_aids;
                                 else
 #endif
-                                yv[u] = (uint32_t)a.p.d_mat_y[m][(size_t)x * (a.p.mat_k[m] > 0 ? a.p.mat_k[m] : K) + l2];
-                                pv[u] = (b & 0xFFFFFFu) + l2;
-                                ok[u] = true;
+                                yv[u] = (uint32_t)*reinterpret_cast<const __attribute__((address_space(1))) int32_t*>(
+                                    (uintptr_t)((((uint64_t)hi << 32) | lo) + (uint64_t)(off + 32u * sw) * 4ull));
                             }
                         }
-                    }
-                    uint32_t nfr = 0;                             // keys this wave entered with this batch
+                        uint32_t nfr = 0;                             // keys this wave entered with this batch
 #pragma unroll
-                    for (int u = 0; u < GU; ++u) {
-                        bool fr = false;
+                        for (int u = 0; u < GU; ++u) {
+                            bool fr = false;
 #ifdef OTTO_PHASE_PROF
-                        if ((a.debug & 1) && ok[u]) { if (yv[u] == 0xDEADBEEFu) s_ovf = 1; ok[u] = false; }
+                            if ((a.debug & 1) && ok[u]) { if (yv[u] == 0xDEADBEEFu) s_ovf = 1; ok[u] = false; }
 #endif
-                        if (ok[u]) {
-                        const uint32_t y = yv[u];
-                        const uint32_t h = y * 0x9E3779B1u;
-                        if (lgR == 0 || ((h >> (32 - lt - lgR)) & (R - 1u)) == part) {
-                            uint32_t slot = h >> (32 - lt);
-                            // double hashing (odd step from a second hash: every slot is visited): linear probing builds
-                            // clusters at the 3/4 load a partition may reach, and a wave waits for its longest chain
-                            const uint32_t step = ((y * 0x85EBCA6Bu) >> (32 - lt)) | 1u;
-                            bool placed = false;
-                            for (int probe = 0; probe < Teff; ++probe) {
-                                // CAS first: a new aid goes in together with its first count. (Measured and dropped in round 3: a
-                                // plain read before the atomics, so that a hit costs one atomic add instead of a failed CAS + add
-                                // + min on its slot: click recipe 115 -> 127 ms.)
-                                const unsigned long long old = atomicCAS(&s_tab[slot], (unsigned long long)CD_EMPTY, ((unsigned long long)y << 32) | 1ull);
-                                const bool fresh = old == CD_EMPTY;
-                                if (fresh || (uint32_t)(old >> 32) == y) {
-                                    if (!fresh) atomicAdd(&s_tab[slot], 1ull);
-                                    fr = fresh;
-                                    atomicMin(&s_fp[slot], pv[u]);
-                                    placed = true;
-                                    break;
+                            if (ok[u]) {
+                                const uint32_t y = yv[u];
+                                const uint32_t h = y * 0x9E3779B1u;
+                                if (lgR == 0 || ((h >> (32 - lt - lgR)) & (R - 1u)) == part) {
+                                    uint32_t slot = h >> (32 - lt);
+                                    // double hashing (odd step from a second hash: every slot is visited): linear probing builds
+                                    // clusters at the 3/4 load a partition may reach, and a wave waits for its longest chain
+                                    const uint32_t step = ((y * 0x85EBCA6Bu) >> (32 - lt)) | 1u;
+                                    bool placed = false;
+                                    for (int probe = 0; probe < Teff; ++probe) {
+                                        // CAS first: a new aid goes in together with its first count. (Measured and dropped in round 3: a
+                                        // plain read before the atomics, so that a hit costs one atomic add instead of a failed CAS + add
+                                        // + min on its slot: click recipe 115 -> 127 ms.)
+                                        const unsigned long long old = atomicCAS(&s_tab[slot], (unsigned long long)CD_EMPTY, ((unsigned long long)y << 32) | 1ull);
+                                        const bool fresh = old == CD_EMPTY;
+                                        if (fresh || (uint32_t)(old >> 32) == y) {
+                                            if (!fresh) atomicAdd(&s_tab[slot], 1ull);
+                                            fr = fresh;
+                                            atomicMin(&s_fp[slot], pv[u]);
+                                            placed = true;
+                                            break;
+                                        }
+                                        slot = (slot + step) & (uint32_t)(Teff - 1);
+                                    }
+                                    if (!placed) s_ovf = 1;
                                 }
-                                slot = (slot + step) & (uint32_t)(Teff - 1);
                             }
-                            if (!placed) s_ovf = 1;
+                            nfr += (uint32_t)__popcll(__ballot(fr));
                         }
-                        }
-                        nfr += (uint32_t)__popcll(__ballot(fr));
+                        // distinct aids of the partition so far: ONE LDS atomic per wave and batch instead of one per new key on the
+                        // same address
+                        if (TOT > (uint32_t)CD_CAP && nfr != 0 && lane == 0 && atomicAdd(&s_nfresh, nfr) + nfr > (uint32_t)CD_CAP) s_ovf = 1;
                     }
-                    // distinct aids of the partition so far: ONE LDS atomic per wave and batch instead of one per new key on the
-                    // same address
-                    if (TOT > (uint32_t)CD_CAP && nfr != 0 && (tid & 63) == 0 && atomicAdd(&s_nfresh, nfr) + nfr > (uint32_t)CD_CAP) s_ovf = 1;
+                    wave_lds_sync();                                  // the segment table is rewritten by the next sweep / batch
                 }
             }
             __syncthreads();
@@ -421,9 +504,13 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                     need = s_keep[0];
                 }
                 const uint64_t thr = all ? 0ull : prefix;              // the NC-th largest order key (the last pass fixes its last digit)
+                uint32_t mine = 0;
+#pragma unroll
+                for (int q = 0; q < MAXC; ++q) mine += (ok[q] != 0 && ok[q] >= thr) ? 1u : 0u;
+                uint32_t at = mine ? atomicAdd(&s_nex, mine) : 0u;    // ONE returning LDS atomic per thread (a round trip), not one per key
 #pragma unroll
                 for (int q = 0; q < MAXC; ++q)
-                    if (ok[q] != 0 && ok[q] >= thr) s_ex[atomicAdd(&s_nex, 1u)] = ck[q];
+                    if (ok[q] != 0 && ok[q] >= thr) s_ex[at++] = ck[q];
                 __syncthreads();
                 const uint32_t nsel = s_nex;                           // <= NC: order keys are distinct
                 if (tid < NC) {
@@ -441,7 +528,6 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
         }
         __syncthreads();
         // ---- drop the session's own aids, compact, write ---------------------------------------------------
-        const uint32_t nU = s_nsrc[0];
         bool keep = false;
         uint32_t y = 0, cnt = 0;
         if (tid < NC) {
@@ -449,9 +535,13 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
             if (c != 0) {
                 y = (uint32_t)(c & 0x3FFFFFFull);
                 cnt = (uint32_t)(c >> 50);
-                keep = true;
-                for (uint32_t j = 0; j < nU; ++j)
-                    if (s_aid[s_src[0][j]] == y) keep = false;
+                uint32_t own = 0;                                 // y among the session's aids (= its unique aids), four events per LDS read
+#pragma unroll 2
+                for (int j0 = 0; j0 < n; j0 += 4) {
+                    const uint4 a4 = *reinterpret_cast<const uint4*>(&s_aid[j0]);
+                    own |= (a4.x == y ? 1u : 0u) | ((a4.y == y && j0 + 1 < n) ? 1u : 0u) | ((a4.z == y && j0 + 2 < n) ? 1u : 0u) | ((a4.w == y && j0 + 3 < n) ? 1u : 0u);
+                }
+                keep = own == 0;
             }
         }
         const uint64_t bal = __ballot(keep);
@@ -468,6 +558,7 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
         for (int i = (int)total + tid; i < NC; i += CD_THREADS) { a.cand[s * NC + i] = -1; a.count[s * NC + i] = 0; }
         if (tid == 0) a.n_out[s] = (int32_t)total;
         __syncthreads();
+        item = s_next[(it + 1u) & 1u];
         CD_PH(6);
     }
 #ifdef OTTO_PHASE_PROF
@@ -839,9 +930,15 @@ static int cand_lookup(const otto_cand_params* p, const uint32_t* d_aid, const u
     if (n_sess <= 0) return 0;
     OTTO_REQUIRE(d_aid && d_type, "null event arrays");
     hipStream_t s = (hipStream_t)stream;
-    uint32_t* d_err = nullptr;
-    OTTO_TRY(device_scratch(SCRATCH_CAND, 4, (void**)&d_err, s));
-    OTTO_HIP(hipMemsetAsync(d_err, 0, 4, s));
+    // scratch: err | sessions per class [2] | dequeue counters [2] | ... | ids of the short sessions | ids of the long sessions
+    OTTO_REQUIRE(n_sess < (1ll << 32), "more than 2^32 sessions");
+    uint32_t* d_hdr = nullptr;
+    OTTO_TRY(device_scratch(SCRATCH_CAND, 64 + 8 * (size_t)n_sess, (void**)&d_hdr, s));
+    OTTO_HIP(hipMemsetAsync(d_hdr, 0, 64, s));
+    uint32_t* d_err = d_hdr;
+    uint32_t* d_short = d_hdr + 16;
+    uint32_t* d_long = d_short + n_sess;
+    k_cand_classify<<<(unsigned)((n_sess + 255) / 256), 256, 0, s>>>(d_sess_off, n_sess, d_hdr + 1, d_short, d_long);
     CandArgs a;
     memset(&a, 0, sizeof a);
     a.p = *p;
@@ -856,15 +953,15 @@ static int cand_lookup(const otto_cand_params* p, const uint32_t* d_aid, const u
     a.debug = getenv("OTTO_CAND_DEBUG") ? atoi(getenv("OTTO_CAND_DEBUG")) : 0;
     (void)hipEventRecord(pe[0], s);
 #endif
-    // short sessions first (most of them), then the long ones; each variant skips the other's sessions
-    a.lo_len = 0; a.hi_len = CD_SMALL_MAXL;
+    // short sessions first (most of them), then the long ones, each from its own work list
+    a.list = d_short; a.list_n = d_hdr + 1; a.work = d_hdr + 3;
     const int grid_s = (int)(n_sess < 256 * 10 ? n_sess : 256 * 10);
     k_cand<CD_SMALL_MAXL, 10, 128><<<grid_s, 128, 0, s>>>(a);
 #ifdef OTTO_PHASE_PROF
     a.prof = d_prof + 8;
     (void)hipEventRecord(pe[1], s);
 #endif
-    a.lo_len = CD_SMALL_MAXL + 1; a.hi_len = 0x7FFFFFFF;
+    a.list = d_long; a.list_n = d_hdr + 2; a.work = d_hdr + 4;
     const int grid = (int)(n_sess < 256 * 2 ? n_sess : 256 * 2);
     k_cand<OTTO_CAND_MAX_SESSION, 12, 512><<<grid, 512, 0, s>>>(a);
 #ifdef OTTO_PHASE_PROF

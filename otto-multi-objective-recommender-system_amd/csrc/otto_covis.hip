@@ -150,12 +150,7 @@ struct ExpandArgs {
     int debug;                   // timing diagnostics (wrong results): 1 no record stores, 2 no row loops
 };
 
-// LDS traffic between the lanes of ONE wave: the LDS queue of a wave is in order, so only the compiler
-// needs a fence -- no workgroup barrier anywhere in this kernel.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
+// (wave_lds_sync: common.h) -- no workgroup barrier anywhere in this kernel.
 
 // G lanes per window, 64/G windows per wave, 4 independent waves per workgroup.
 //  A: load the window; class id of an event = first position holding the same aid.
