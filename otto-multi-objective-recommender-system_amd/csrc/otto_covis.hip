@@ -2526,6 +2526,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 wave_lds_sync();
             }
         }
+        OTTO_PH(4);                            // one-wave bin: p4 = its whole top-k, p0 = the wait for the next item's words
         } else if constexpr (NW == 1) {
         bool fast_done = false;
         OTTO_PH(7);
