@@ -53,14 +53,36 @@ __device__ __forceinline__ uint64_t cand_key(uint64_t count, uint32_t fp, uint32
     return (count << 50) | ((uint64_t)(0xFFFFFFu - fp) << 26) | (uint64_t)y;
 }
 
-// Sessions by length class: hdr[0] / hdr[1] = number of short (<= CD_SMALL_MAXL events) / long sessions, their ids in lists[0] / lists[1]
+// Work-list dequeue of the per-session kernels (thread 0 of a workgroup): sessions are reserved CD_DQ at a time -- same-address
+// atomics retire at ~90 M/s, one per session would bound 1.6 M short sessions at 17 ms -- and the next chunk is requested when the
+// current one is opened, so its round trip is never waited for.
+constexpr uint32_t CD_DQ = 8;
+struct WorkPool {
+    uint32_t pool, pool_end, pool_next;
+    __device__ __forceinline__ void init(uint32_t* counter) {
+        pool = atomicAdd(counter, 2 * CD_DQ);
+        pool_end = pool + CD_DQ;
+        pool_next = pool + CD_DQ;
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t* counter) {
+        const uint32_t r = pool++;
+        if (pool == pool_end) {
+            pool = pool_next;
+            pool_end = pool + CD_DQ;
+            pool_next = atomicAdd(counter, CD_DQ);
+        }
+        return r;
+    }
+};
+
+// Sessions by length class: hdr[0] / hdr[1] = number of short (<= short_max events) / long sessions, their ids in lists[0] / lists[1]
 // (n_sess entries each). One returning atomic per wave and class.
-__global__ __launch_bounds__(256) void k_cand_classify(const int64_t* sess_off, int64_t n_sess, uint32_t* hdr, uint32_t* list_short, uint32_t* list_long) {
+__global__ __launch_bounds__(256) void k_cand_classify(const int64_t* sess_off, int64_t n_sess, int short_max, uint32_t* hdr, uint32_t* list_short, uint32_t* list_long) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const unsigned lane = lane_id();
     const bool in = s < n_sess;
     const int64_t n = in ? sess_off[s + 1] - sess_off[s] : 0;
-    const bool is_long = in && n > CD_SMALL_MAXL;
+    const bool is_long = in && n > short_max;
     const uint64_t ml = __ballot(is_long), ms = __ballot(in && !is_long);
     uint32_t bl = 0, bs = 0;
     if (lane == 0) {
@@ -109,12 +131,12 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
 
     __shared__ uint32_t s_next[2];
     const uint32_t n_list = *a.list_n;
-    if (tid == 0) s_next[0] = atomicAdd(a.work, 1u);
+    WorkPool wp;
+    if (tid == 0) { wp.init(a.work); s_next[0] = wp.take(a.work); }
     __syncthreads();
     uint32_t item = s_next[0];
     for (uint32_t it = 0; item < n_list; ++it) {
-        // the next session is dequeued now: the counter's round trip is over long before this session is
-        if (tid == 0) s_next[(it + 1u) & 1u] = atomicAdd(a.work, 1u);
+        if (tid == 0) s_next[(it + 1u) & 1u] = wp.take(a.work);         // read at the end of this session
         const int64_t s = (int64_t)a.list[item];
         const int64_t lo = a.sess_off[s], hi = a.sess_off[s + 1];
         const int n = (int)(hi - lo);
@@ -685,7 +707,9 @@ struct RecencyArgs {
     double* out_w;
     int32_t* n_out;
     uint32_t* err;
-    int lo_len, hi_len;
+    const uint32_t* list;          // this launch's sessions (k_cand_classify at 64 events) / their number / dequeue counter
+    const uint32_t* list_n;
+    uint32_t* work;
 };
 
 // One workgroup per session (THREADS = 64 for sessions up to 64 events, 256 beyond). Event i: weight of every curve
@@ -701,12 +725,21 @@ __global__ __launch_bounds__(THREADS) void k_recency(RecencyArgs a) {
     __shared__ uint32_t s_nu;
     const int tid = threadIdx.x;
     const int NCV = a.p.n_curves;
-    for (int64_t s = blockIdx.x; s < a.n_sess; s += gridDim.x) {
+    __shared__ uint32_t s_next[2];
+    const uint32_t n_list = *a.list_n;
+    WorkPool wp;
+    if (tid == 0) { wp.init(a.work); s_next[0] = wp.take(a.work); }
+    __syncthreads();
+    uint32_t item = s_next[0];
+    for (uint32_t it = 0; item < n_list; ++it) {
+        if (tid == 0) s_next[(it + 1u) & 1u] = wp.take(a.work);         // read at the end of this session
+        const int64_t s = (int64_t)a.list[item];
         const int64_t lo = a.sess_off[s], hi = a.sess_off[s + 1];
         const int n = (int)(hi - lo);
-        if (n < a.lo_len || n > a.hi_len) continue;
         if (n > MAXL) {
             if (tid == 0) atomicAdd(a.err, 1u);
+            __syncthreads();
+            item = s_next[(it + 1u) & 1u];
             continue;
         }
         if (tid == 0) s_nu = 0;
@@ -755,6 +788,7 @@ __global__ __launch_bounds__(THREADS) void k_recency(RecencyArgs a) {
         }
         if (tid == 0) a.n_out[s] = (int32_t)s_nu;
         __syncthreads();
+        item = s_next[(it + 1u) & 1u];
     }
 }
 
@@ -891,17 +925,23 @@ extern "C" int otto_recency_candidates(const otto_recency_params* p, const uint3
     if (n_sess <= 0) return 0;
     OTTO_REQUIRE(d_aid && d_type, "null event arrays");
     hipStream_t s = (hipStream_t)stream;
-    uint32_t* d_err = nullptr;
-    OTTO_TRY(device_scratch(SCRATCH_RECENCY, 4, (void**)&d_err, s));
-    OTTO_HIP(hipMemsetAsync(d_err, 0, 4, s));
+    // scratch: err | sessions per class [2] | dequeue counters [2] | ... | ids of the sessions of <= 64 events | ids of the others
+    OTTO_REQUIRE(n_sess < (1ll << 32), "more than 2^32 sessions");
+    uint32_t* d_hdr = nullptr;
+    OTTO_TRY(device_scratch(SCRATCH_RECENCY, 64 + 8 * (size_t)n_sess, (void**)&d_hdr, s));
+    OTTO_HIP(hipMemsetAsync(d_hdr, 0, 64, s));
+    uint32_t* d_err = d_hdr;
+    uint32_t* d_short = d_hdr + 16;
+    uint32_t* d_long = d_short + n_sess;
+    k_cand_classify<<<(unsigned)((n_sess + 255) / 256), 256, 0, s>>>(d_sess_off, n_sess, 64, d_hdr + 1, d_short, d_long);
     RecencyArgs a;
     memset(&a, 0, sizeof a);
     a.p = *p;
     a.aid = d_aid; a.type = d_type; a.sess_off = d_sess_off; a.n_sess = n_sess; a.n_events = n_events;
     a.out_aid = d_out_aid; a.out_w = d_out_w; a.n_out = d_n; a.err = d_err;
-    a.lo_len = 0; a.hi_len = 64;
+    a.list = d_short; a.list_n = d_hdr + 1; a.work = d_hdr + 3;
     k_recency<64, 64><<<(int)(n_sess < 256 * 32 ? n_sess : 256 * 32), 64, 0, s>>>(a);
-    a.lo_len = 65; a.hi_len = 0x7FFFFFFF;
+    a.list = d_long; a.list_n = d_hdr + 2; a.work = d_hdr + 4;
     k_recency<OTTO_CAND_MAX_SESSION, 256><<<(int)(n_sess < 256 * 8 ? n_sess : 256 * 8), 256, 0, s>>>(a);
     hipError_t le = hipGetLastError();
     uint32_t h_err = 0;
@@ -938,7 +978,7 @@ static int cand_lookup(const otto_cand_params* p, const uint32_t* d_aid, const u
     uint32_t* d_err = d_hdr;
     uint32_t* d_short = d_hdr + 16;
     uint32_t* d_long = d_short + n_sess;
-    k_cand_classify<<<(unsigned)((n_sess + 255) / 256), 256, 0, s>>>(d_sess_off, n_sess, d_hdr + 1, d_short, d_long);
+    k_cand_classify<<<(unsigned)((n_sess + 255) / 256), 256, 0, s>>>(d_sess_off, n_sess, CD_SMALL_MAXL, d_hdr + 1, d_short, d_long);
     CandArgs a;
     memset(&a, 0, sizeof a);
     a.p = *p;

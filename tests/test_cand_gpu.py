@@ -66,6 +66,24 @@ def test_candidates_long_sessions_use_hash_partitions(gpu_device):
     _check(ev, val, gpu_device, (cdo.CLICK_RECIPE, cdo.ORDER_RECIPE))
 
 
+@pytest.mark.parametrize('n_common,k', [(1, 20), (37, 7), (64, 20), (65, 15), (128, 32)])
+def test_candidates_selection_sizes_and_length_classes(gpu_device, n_common, k):
+    """The radix select of most_common(n) at its edges (n = 1, one short of / one past a 64-lane wave, the maximum 128; lists of
+    7 / 15 / 32 entries = partial, two and four 8-entry segments) and the work lists of the two kernel variants: sessions of
+    exactly 32 and 33 events (class boundary), an empty session between them, one event, one repeated aid."""
+    rng = np.random.default_rng(100 + n_common)
+    ev = generate_sessions(8000, n_aids=900, seed=21)
+    L = np.array([32, 0, 33, 1, 40, 32, 33, 5, 64, 65, 2, 31, 130, 3, 0, 12])
+    off = np.r_[0, np.cumsum(L)].astype(np.int64)
+    aid = rng.integers(0, 900, off[-1]).astype(np.uint32)
+    aid[off[4]:off[5]] = 5                                   # 40 events of one aid
+    typ = rng.integers(0, 3, off[-1]).astype(np.uint8)
+    val = Events(aid=aid, ts=np.zeros(off[-1], dtype=np.int32), type=typ, sess_off=off, n_aids=900)
+    _check(ev, val, gpu_device, (cdo.CLICK_RECIPE, cdo.CART_RECIPE), n_common=n_common, k=k)
+    more = generate_sessions(400, n_aids=900, seed=22 + k)
+    _check(ev, more, gpu_device, (cdo.ORDER_RECIPE,), n_common=n_common, k=k)
+
+
 def test_recency_weighted_candidates_match_reference_loop(gpu_device):
     """Section 8 f3: order identical to Counter.most_common, float64 weights within 1e-12 relative (the device exp2 may
     differ from NumPy's pow in the last unit). Sessions of 1 event, of one repeated aid, and of 300+ events included."""
