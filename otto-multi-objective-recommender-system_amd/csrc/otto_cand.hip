@@ -20,7 +20,6 @@
 namespace otto {
 
 constexpr uint64_t CD_EMPTY = ~0ull;
-constexpr int CD_EXCAP = 64;
 constexpr int CD_SMALL_MAXL = 32;
 constexpr int CD_STACK = 96;                          // partitions waiting (first level <= 64) + refinements                     // sessions up to this many events run in the small-footprint variant
 
@@ -117,7 +116,6 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
     __shared__ uint64_t s_sel[OTTO_CAND_MAX_COMMON];   // running most_common list (sorted)
     __shared__ uint64_t s_lb[CD_THREADS];
     __shared__ uint64_t s_ex[OTTO_CAND_MAX_COMMON];
-    __shared__ uint64_t s_thr;
     __shared__ uint32_t s_nex, s_more, s_ovf, s_nfresh, s_sp, s_scan[CD_NW + 1], s_keep[2], s_maxlen;
     __shared__ uint32_t s_stack[CD_STACK];            // hash partitions still to do: id | level << 24
     __shared__ uint8_t s_seg[CD_NW * 256];            // gather: segment -> list lane << 2 | segment of the list, per wave
@@ -477,7 +475,7 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                 }
                 uint32_t* hist = reinterpret_cast<uint32_t*>(s_lb);   // 256 bins (s_lb: CD_THREADS x 8 bytes >= 1 KB)
                 for (int i = tid; i < 256; i += CD_THREADS) hist[i] = 0;
-                if (tid == 0) { s_nex = 0; s_thr = 0; }
+                if (tid == 0) s_nex = 0;
                 // a key occurs at most once per list: count <= Q
                 const int W = TB + (32 - __clz((int)(Q | 1u)));
                 const int P = (W + 7) >> 3;

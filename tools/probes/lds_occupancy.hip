@@ -13,11 +13,11 @@ __global__ __launch_bounds__(THREADS) void k(uint32_t* out) {
 template <int BYTES, int THREADS>
 void probe() {
     int n = 0;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k<BYTES, THREADS>, THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k<BYTES, THREADS>, THREADS, 0);
     printf("LDS %6d B, %4d threads: %d workgroups per CU\n", BYTES, THREADS, n);
 }
 int main() {
-    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+    hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
     printf("%s: CUs %d, sharedMemPerBlock %zu, maxSharedMemoryPerMultiProcessor %zu\n", p.gcnArchName, p.multiProcessorCount, p.sharedMemPerBlock, p.maxSharedMemoryPerMultiProcessor);
     probe<32768, 256>(); probe<37924, 256>(); probe<40848, 256>(); probe<40960, 256>(); probe<42020, 256>(); probe<49152, 256>();
     probe<53248, 256>(); probe<54000, 256>(); probe<65536, 256>(); probe<81584, 512>(); probe<7176, 64>(); probe<8192, 64>();
