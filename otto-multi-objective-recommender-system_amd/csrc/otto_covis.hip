@@ -2056,7 +2056,10 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     // item's top-k (after its last walk over the table), so a one-workgroup-per-CU kernel no longer sits through the whole
     // HBM round trip + the CU's ingest time (48 KB at ~24 GB/s) between two items.
     constexpr int BU = GROUP == OTTO_COVIS_GROUP_TIME ? 4 : ((PACKED && THREADS == L_THREADS) ? 12 : 6);
-    constexpr bool PREF = THREADS == L_THREADS && GROUP != OTTO_COVIS_GROUP_TIME;   // the kernels that read partition buckets
+    constexpr bool PREF = THREADS == L_THREADS && GROUP != OTTO_COVIS_GROUP_TIME;   // the 1024-thread kernels that read partition buckets
+    // the 512-thread kernel has no registers to hold a prefetched round (6 more live values spill, and a spill waits for the
+    // load): it only touches the next bucket's lines early (WARM), the loads of the item itself then come from L2
+    constexpr bool WARM = (THREADS == L_THREADS || THREADS == 512) && GROUP != OTTO_COVIS_GROUP_TIME;
     uint32_t pre[PREF ? BU : 1];
     bool pre_valid = false;                // uniform: pre[] holds the first round of the item that becomes `cur` next
     auto prefetch_next = [&]() {
@@ -2910,8 +2913,16 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 if (j < a.nk && !kvalid(guess[j])) gv = false;
             if (gv) {                                    // uniform: every thread loaded the same words
                 if (threadIdx.x < PK) s_nex[threadIdx.x] = 0;
-                if (threadIdx.x == 0) s_more = 0;
+                if (threadIdx.x == 0) { s_more = 0; if (WARM) s_nxt = nx; }
                 __syncthreads();
+                // the next item's bucket is touched now, one 64-byte line per thread, so that the prefetch below (which must wait
+                // for the last walk over the table: it holds BU registers per lane) finds it in L2 instead of HBM -- the records
+                // of a partition arrived 16 % of the kernel's time after they were asked for
+                uint32_t warm = 0;
+                if (WARM && s_nxt.it != 0xFFFFFFFFu && (s_nxt.item >> 50) != 0 && a.pstart != nullptr) {
+                    const uint64_t wi = s_nxt.ps + (uint64_t)threadIdx.x * 16u;
+                    if (wi < s_nxt.pe) warm = a.prec[wi];
+                }
                 for (int q = 0; q < nit; ++q) {
                     const int sl = slot_at(q);
                     if (sl < 0) continue;
@@ -2921,7 +2932,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                     for (int j = 0; j < PKD; ++j)
                         if (j < a.nk && kvalid(kk[j]) && kbetter(kk[j], guess[j])) append(j, kk[j]);
                 }
-                if (PREF && threadIdx.x == 0) s_nxt = nx;
+                asm volatile("" :: "v"(warm));            // the touch is a real load: its value is dropped here
                 __syncthreads();
                 prefetch_next();                         // last walk over the table done: request the next item's records
                 pre_issued = true;
