@@ -17,4 +17,7 @@ cp $E/pytest_gpu.log $P/pytest_gpu.log
 cp $E/next_rows_perf.log $P/next_rows_perf.log
 cp $E/k1_debug_skip.log $P/k1_debug_skip.log
 grep -v "amdgpu.ids" $E/phase_split.log > $P/phase_split_reduce.log
+cp $E/cand_pmc_summary.txt $P/cand_pmc_summary.txt
+cp $E/cand_phase_split.log $P/cand_phase_split.log
+grep -v "rep 0" $E/cand_perf.log > $P/cand_perf.log
 ls -la $P
