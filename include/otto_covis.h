@@ -117,12 +117,17 @@ int otto_covis_stats(otto_covis_ctx* ctx, int64_t* out /* [OTTO_COVIS_STAT_COUNT
  *   "l_cap": expanded pairs per hash partition of a heavy aid_x in the wide table layout (default 6144; the packed
  *            2^14-slot layout takes twice as many);
  *   "partition": 1 (default) bucket heavy aids' pairs by partition once, 0 re-read and filter per partition;
- *   "fused": 1 (default) fused in-order register pair-expand kernel when no filter kind is configured, 0 class-sorted kernels;
+ *   "fused": pair-expand kernel when no filter kind is configured: 2 (default) component lists (k_expand_lists), 1 one record per
+ *            pair from registers (k_expand_fused), 0 class-sorted kernels;
  *   "fast_path": 1 (default) gap-free window shortcut in the pair-expand kernels;
  *   "bucket_index": 1 (default) group the runs by aid_x with LDS atomics per 1024-aid bucket, 0 one global atomic per run;
  *   "packed_heavy": packed 12-bit-counter tables for heavy aids with fewer than 4096 runs: 2 (default) 2^14 slots for aids that
  *                   fit one table, 2^13-slot partitions beyond; 1: 2^14-slot partitions of twice the size; 0: wide tables only;
  *   "guess": 1 (default) single-pass top-k of a heavy aid's partitions from a sibling partition's threshold;
+ *   "hot": 2 (default) top-k walks over the heavy keys only + single-wave selection where they are few, 1 walks only, 0 off;
+ *   "bkt_sh": log2 of the aids per index bucket (default clamp(aid_bits - 10, 10, 13)); "part_sized": 1 (default) partition buckets
+ *            sized from the record counts without a count pass; "overlap_partition": 1 partition pass on a side stream beside the
+ *            S / M bins (default 0); "s_wgs" / "p_wgs": workgroups per CU of the one-wave reduce bin (20) / the partition scatter (12);
  *   "debug_skip": timing diagnostics only (results invalid): 1 no gather, 2 no top-k, 4 no table clear, 8 no inserts,
  *                 16 / 32 pair-expand without record stores / row loops. */
 int otto_covis_set_option(otto_covis_ctx* ctx, const char* name, int64_t value);

@@ -157,40 +157,66 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
         // operation (one 16-byte read of aids, one 4-byte read of types / flags) and without branches: with two workgroups per
         // CU and most waves of a workgroup waiting at the barrier, a loop of one dependent LDS read per event ran at one LDS round
         // trip per event (a quarter of the long-session kernel).
-        for (int i = tid; i < n; i += CD_THREADS) {
-            const uint32_t ai = s_aid[i];
-            const uint32_t ti = s_ty[i];
-            uint32_t later = 0, pcc = 0, pco = 0, pc = 0;        // same aid: later / earlier with type <= 1 / >= 1 / == 0
+        // SUB adjacent lanes share an event and split the session between them (n = 82 on 512 threads: 4 lanes per event, a
+        // quarter of the loop each; partial results are combined with DPP exchanges): the loop length, not the thread count, is
+        // what these two passes wait for.
+        int lgsub = 0;
+        while (lgsub < 3 && (n << (lgsub + 1)) <= CD_THREADS) ++lgsub;
+        const int SUB = 1 << lgsub;
+        const int ev_i = tid >> lgsub, sub = tid & (SUB - 1);
+        const int jlen = (((n + SUB - 1) >> lgsub) + 3) & ~3;      // events per lane of a group, a multiple of 4
+        const int jb = sub * jlen, je = (jb + jlen < n) ? jb + jlen : n;
+        auto group_or = [&](uint32_t v) {
+            if (lgsub >= 1) v |= xor_lane32(v, 1);
+            if (lgsub >= 2) v |= xor_lane32(v, 2);
+            if (lgsub >= 3) v |= xor_lane32(v, 4);
+            return v;
+        };
+        auto group_add = [&](uint32_t v) {
+            if (lgsub >= 1) v += xor_lane32(v, 1);
+            if (lgsub >= 2) v += xor_lane32(v, 2);
+            if (lgsub >= 3) v += xor_lane32(v, 4);
+            return v;
+        };
+        for (int i0 = 0; i0 < n; i0 += CD_THREADS >> lgsub) {      // one pass unless n > CD_THREADS / 2 (then SUB = 1)
+            const int i = i0 + ev_i;
+            const bool act = i < n;
+            const uint32_t ai = act ? s_aid[i] : 0u;
+            const uint32_t ti = act ? s_ty[i] : 0u;
+            uint32_t acc = 0;                                      // bit 0 same aid later, bits 1 / 2 / 3 same aid earlier with type <= 1 / >= 1 / == 0
+            if (act) {
 #pragma unroll 2
-            for (int j0 = 0; j0 < n; j0 += 4) {
-                const uint4 a4 = *reinterpret_cast<const uint4*>(&s_aid[j0]);
-                const uint32_t t4 = *reinterpret_cast<const uint32_t*>(&s_ty[j0]);
-                const uint32_t aj[4] = {a4.x, a4.y, a4.z, a4.w};
+                for (int j0 = jb; j0 < je; j0 += 4) {
+                    const uint4 a4 = *reinterpret_cast<const uint4*>(&s_aid[j0]);
+                    const uint32_t t4 = *reinterpret_cast<const uint32_t*>(&s_ty[j0]);
+                    const uint32_t aj[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int j = j0 + e;
-                    const uint32_t tj = (t4 >> (8 * e)) & 0xFFu;
-                    const uint32_t eq = (aj[e] == ai && j < n) ? 1u : 0u;
-                    const uint32_t before = eq & (j < i ? 1u : 0u);
-                    later |= eq & (j > i ? 1u : 0u);
-                    pcc |= before & (tj <= 1u ? 1u : 0u);
-                    pco |= before & (tj >= 1u ? 1u : 0u);
-                    pc |= before & (tj == 0u ? 1u : 0u);
+                    for (int e = 0; e < 4; ++e) {
+                        const int j = j0 + e;
+                        const uint32_t tj = (t4 >> (8 * e)) & 0xFFu;
+                        const uint32_t eq = (aj[e] == ai && j < n) ? 1u : 0u;
+                        const uint32_t before = eq & (j < i ? 1u : 0u);
+                        acc |= (eq & (j > i ? 1u : 0u)) | ((before & (tj <= 1u ? 1u : 0u)) << 1) | ((before & (tj >= 1u ? 1u : 0u)) << 2) |
+                               ((before & (tj == 0u ? 1u : 0u)) << 3);
+                    }
                 }
             }
-            const bool last = later == 0, fcc = ti <= 1 && pcc == 0, fco = ti >= 1 && pco == 0, fc = ti == 0 && pc == 0;
-            s_flag[i] = (uint8_t)((last ? 1 : 0) | (fcc ? 2 : 0) | (fco ? 4 : 0) | (fc ? 8 : 0));
+            acc = group_or(acc);
+            if (act && sub == 0) {
+                const bool last = (acc & 1u) == 0, fcc = ti <= 1 && (acc & 2u) == 0, fco = ti >= 1 && (acc & 4u) == 0, fc = ti == 0 && (acc & 8u) == 0;
+                s_flag[i] = (uint8_t)((last ? 1 : 0) | (fcc ? 2 : 0) | (fco ? 4 : 0) | (fc ? 8 : 0));
+            }
         }
         __syncthreads();
-        for (int i0 = 0; i0 < n; i0 += CD_THREADS) {            // (uniform trip count: the list sizes come from wave ballots)
-            const int i = i0 + tid;
+        for (int i0 = 0; i0 < n; i0 += CD_THREADS >> lgsub) {      // (uniform trip count: the list sizes come from wave ballots)
+            const int i = i0 + ev_i;
+            const bool act = i < n;
             uint32_t fl = 0;
-            if (i < n) {
-                const uint32_t ai = s_aid[i];
-                fl = s_flag[i];
-                uint32_t ru = 0, rcc = 0, rco = 0, rc = 0;
+            uint32_t r01 = 0, r23 = 0;                             // ranks, two 16-bit counters per word: ru | rcc << 16, rco | rc << 16
+            const uint32_t ai = act ? s_aid[i] : 0u;
+            if (act) {
 #pragma unroll 2
-                for (int j0 = 0; j0 < n; j0 += 4) {
+                for (int j0 = jb; j0 < je; j0 += 4) {
                     const uint4 a4 = *reinterpret_cast<const uint4*>(&s_aid[j0]);
                     const uint32_t f4 = *reinterpret_cast<const uint32_t*>(&s_flag[j0]);
                     const uint32_t aj[4] = {a4.x, a4.y, a4.z, a4.w};
@@ -199,16 +225,19 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                         const int j = j0 + e;
                         const uint32_t fj = j < n ? (f4 >> (8 * e)) & 0xFFu : 0u;
                         const uint32_t lt = aj[e] < ai ? 1u : 0u;
-                        ru += (j > i ? 1u : 0u) & (fj & 1u);
-                        rcc += ((fj >> 1) & 1u) & lt;
-                        rco += ((fj >> 2) & 1u) & lt;
-                        rc += ((fj >> 3) & 1u) & lt;
+                        r01 += ((j > i ? 1u : 0u) & (fj & 1u)) | ((((fj >> 1) & 1u) & lt) << 16);
+                        r23 += (((fj >> 2) & 1u) & lt) | ((((fj >> 3) & 1u) & lt) << 16);
                     }
                 }
-                if (fl & 1u) s_src[0][ru] = (uint16_t)i;
-                if (fl & 2u) s_src[1][rcc] = (uint16_t)i;
-                if (fl & 4u) s_src[2][rco] = (uint16_t)i;
-                if (fl & 8u) s_src[3][rc] = (uint16_t)i;
+            }
+            r01 = group_add(r01);
+            r23 = group_add(r23);
+            if (act && sub == 0) {
+                fl = s_flag[i];
+                if (fl & 1u) s_src[0][r01 & 0xFFFFu] = (uint16_t)i;
+                if (fl & 2u) s_src[1][r01 >> 16] = (uint16_t)i;
+                if (fl & 4u) s_src[2][r23 & 0xFFFFu] = (uint16_t)i;
+                if (fl & 8u) s_src[3][r23 >> 16] = (uint16_t)i;
             }
             // list sizes: one LDS atomic per wave and list instead of one per event on the same address
             const uint32_t c0 = (uint32_t)__popcll(__ballot(fl & 1u)), c1 = (uint32_t)__popcll(__ballot(fl & 2u));
@@ -449,8 +478,8 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
             // ---- most_common(NC) of this partition's table + the list carried over from the earlier partitions ----
             // Order: count descending, first position ascending (first positions are distinct: one aid per position of the
             // concatenation), i.e. the ORDER KEY  count << TB | (2^TB - 1 - first position)  with TB = bits of TOT. The
-            // NC-th largest order key is found exactly by a most-significant-digit radix select (8-bit digits, 2 - 3 passes
-            // for count < 2^8 and TOT < 2^13): every thread keeps its <= 9 candidates in registers, a pass is one LDS histogram
+            // NC-th largest order key is found exactly by a most-significant-digit radix select (8- or 10-bit digits, 2 passes
+            // for count < 2^8 and TOT < 2^12): every thread keeps its <= 9 candidates in registers, a pass is one LDS histogram
             // of the candidates that match the digits fixed so far + one 256-bin scan by wave 0. Then the selected keys (exactly
             // NC of them, or every candidate) are compacted and ranked by counting. All waves work in every step; the former
             // path (lane bests -> 64-lane sort -> one-by-one pushes into a sorted list held by wave 0, two rounds of 64) cost
@@ -473,22 +502,26 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                     ck[q] = c;
                     ok[q] = c ? (((c >> 50) << TB) | (((c >> 26) & 0xFFFFFFull) - fpb)) : 0ull;
                 }
-                uint32_t* hist = reinterpret_cast<uint32_t*>(s_lb);   // 256 bins (s_lb: CD_THREADS x 8 bytes >= 1 KB)
-                for (int i = tid; i < 256; i += CD_THREADS) hist[i] = 0;
+                // digits of DB bits: 10 where the histogram fits (512 threads: s_lb is 4 KB), 8 otherwise -- two passes instead of
+                // three for the long sessions (count < 2^8, TOT < 2^12)
+                constexpr int DB = CD_THREADS * 8 >= 4096 ? 10 : 8;
+                constexpr int NBIN = 1 << DB, BPL = NBIN / 64;         // bins, bins per lane of the scanning wave
+                uint32_t* hist = reinterpret_cast<uint32_t*>(s_lb);   // NBIN bins (s_lb: CD_THREADS x 8 bytes)
+                for (int i = tid; i < NBIN; i += CD_THREADS) hist[i] = 0;
                 if (tid == 0) s_nex = 0;
                 // a key occurs at most once per list: count <= Q
                 const int W = TB + (32 - __clz((int)(Q | 1u)));
-                const int P = (W + 7) >> 3;
-                uint64_t prefix = 0;                                  // the digits fixed so far (order key >> (shift + 8))
+                const int P = (W + DB - 1) / DB;
+                uint64_t prefix = 0;                                  // the digits fixed so far (order key >> (shift + DB))
                 uint32_t need = (uint32_t)NC;
                 bool all = false;                                     // fewer candidates than NC: every candidate is selected
                 __syncthreads();
                 for (int pass = 0; pass < P; ++pass) {
-                    const int shift = 8 * (P - 1 - pass);
+                    const int shift = DB * (P - 1 - pass);
 #pragma unroll
                     for (int q = 0; q < MAXC; ++q) {
-                        const bool in = ok[q] != 0 && (ok[q] >> (shift + 8)) == prefix;
-                        const uint32_t d = (uint32_t)(ok[q] >> shift) & 255u;
+                        const bool in = ok[q] != 0 && (ok[q] >> (shift + DB)) == prefix;
+                        const uint32_t d = (uint32_t)(ok[q] >> shift) & (uint32_t)(NBIN - 1);
                         // most candidates of a wave share the digit (small counts): one add for all of them
                         const uint64_t m_in = __ballot(in);
                         if (m_in == 0) continue;
@@ -499,28 +532,35 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                     }
                     __syncthreads();
                     if (wid == 0) {
-                        const uint4 h = reinterpret_cast<const uint4*>(hist)[lane];            // bins 4 lane .. 4 lane + 3
-                        reinterpret_cast<uint4*>(hist)[lane] = make_uint4(0u, 0u, 0u, 0u);      // cleared for the next pass
-                        const uint32_t sum = h.x + h.y + h.z + h.w;
+                        uint32_t h[BPL];                              // bins BPL lane .. BPL lane + BPL - 1
+                        uint32_t sum = 0;
+#pragma unroll
+                        for (int v = 0; v < BPL / 4; ++v) {
+                            const uint4 h4 = reinterpret_cast<const uint4*>(hist)[lane * (BPL / 4) + v];
+                            reinterpret_cast<uint4*>(hist)[lane * (BPL / 4) + v] = make_uint4(0u, 0u, 0u, 0u);   // cleared for the next pass
+                            h[4 * v] = h4.x; h[4 * v + 1] = h4.y; h[4 * v + 2] = h4.z; h[4 * v + 3] = h4.w;
+                            sum += h4.x + h4.y + h4.z + h4.w;
+                        }
                         const uint32_t incl = wave_incl_scan(sum);
                         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                        const uint32_t a3 = total - incl, a2 = a3 + h.w, a1 = a2 + h.z, a0 = a1 + h.y;    // candidates in the bins above bin 3, 2, 1, 0 of this lane
                         if (pass == 0 && total < need) {
                             if (lane == 0) s_more = 0xFFFFFFFFu;       // take every candidate
                         } else {
+                            uint32_t above = total - incl;             // candidates in the bins above this lane's
                             int b = -1;
-                            uint32_t above = 0;
-                            if (a3 < need && need <= a3 + h.w) { b = 3; above = a3; }
-                            else if (a2 < need && need <= a2 + h.z) { b = 2; above = a2; }
-                            else if (a1 < need && need <= a1 + h.y) { b = 1; above = a1; }
-                            else if (a0 < need && need <= a0 + h.x) { b = 0; above = a0; }
-                            if (b >= 0) { s_more = 4u * lane + (uint32_t)b; s_keep[0] = need - above; }
+                            uint32_t above_b = 0;
+#pragma unroll
+                            for (int v = BPL - 1; v >= 0; --v) {
+                                if (b < 0 && above < need && need <= above + h[v]) { b = v; above_b = above; }
+                                above += h[v];
+                            }
+                            if (b >= 0) { s_more = (uint32_t)BPL * lane + (uint32_t)b; s_keep[0] = need - above_b; }
                         }
                     }
                     __syncthreads();
                     const uint32_t dsel = s_more;
                     if (dsel == 0xFFFFFFFFu) { all = true; break; }
-                    prefix = (prefix << 8) | dsel;
+                    prefix = (prefix << DB) | dsel;
                     need = s_keep[0];
                 }
                 const uint64_t thr = all ? 0ull : prefix;              // the NC-th largest order key (the last pass fixes its last digit)

@@ -23,7 +23,7 @@ cd /root/repo
 (python tools/pmc_sq_summarize.py $E/cand_sq | grep -i "ratios\|cand\|recency"; python tools/pmc_inst_summarize.py $E/cand_inst | grep -i "cand\|recency") > $E/cand_pmc_summary.txt 2>&1
 timeout -k 10 300 python tools/perf_cand.py --reps 2 > $E/cand_perf.log 2>&1; grep -v "rep 0" $E/cand_perf.log | tail -n 8
 : > $E/cand_phase_split.log
-for d in 0 1 2 3; do echo "OTTO_CAND_DEBUG=$d (1 no inserts, 2 no list loads)" >> $E/cand_phase_split.log; OTTO_CAND_DEBUG=$d OTTO_AMD_LIB=$PWD/otto-multi-objective-recommender-system_amd/csrc/libotto_amd_prof.so timeout -k 10 300 python tools/perf_cand.py --reps 1 2>&1 | grep "phase-prof. k_cand" | head -n 2 >> $E/cand_phase_split.log; done
+for d in 0 1; do echo "OTTO_CAND_DEBUG=$d (1: no inserts -- the tables stay empty, so the selection is trivial too)" >> $E/cand_phase_split.log; OTTO_CAND_DEBUG=$d OTTO_AMD_LIB=$PWD/otto-multi-objective-recommender-system_amd/csrc/libotto_amd_prof.so timeout -k 10 300 python tools/perf_cand.py --reps 1 2>&1 | grep "phase-prof. k_cand" | head -n 2 >> $E/cand_phase_split.log; done
 echo "== next rows"; timeout -k 10 400 python tools/perf_next_rows.py > $E/next_rows_perf.log 2>&1; tail -5 $E/next_rows_perf.log
 echo "== bench under rocprof"; cd /tmp; timeout -k 10 700 rocprofv3 --kernel-trace --stats -d /root/repo/$E/prof -o r1 --output-format csv -- python /root/repo/bench.py > /root/repo/$E/bench_rocprof.log 2>&1; cd /root/repo; grep '"metric"' $E/bench_rocprof.log | cut -c1-300
 echo "== plain bench"; timeout -k 10 600 python bench.py > $E/bench_plain.log 2>&1; grep '"metric"' $E/bench_plain.log | cut -c1-300
