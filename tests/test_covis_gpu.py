@@ -215,6 +215,25 @@ def test_heavy_aid_partitions_and_overflow_retry(gpu_device):
     _assert_rows_equal(got2, want, kinds)
 
 
+@pytest.mark.parametrize('l_cap', [64, 256, 1024])
+def test_partition_scatter_paths_by_partition_count(gpu_device, l_cap):
+    """A hub aid of ~58 k pairs cut into partitions of l_cap pairs: l_cap = 64 -> 1024 partitions, above what the partition pass
+    stages in LDS (512: its direct scatter path with one global cursor bump per record); 256 -> 256 partitions and 1024 -> 64, the
+    staged path with many / few partitions per chunk. With and without the time channel travelling along."""
+    rng = np.random.default_rng(11)
+    S, n_aids = 2000, 30000
+    aid = rng.integers(1, n_aids, size=(S, 30)).astype(np.uint32)
+    aid[np.arange(S), rng.integers(0, 30, S)] = 0
+    ts = (1_660_000_000 + np.cumsum(rng.integers(1, 50, size=(S, 30)), axis=1)).astype(np.int32)
+    typ = rng.integers(0, 3, size=(S, 30)).astype(np.uint8)
+    ev = Events(aid=aid.ravel(), ts=ts.ravel(), type=typ.ravel(), sess_off=np.arange(S + 1, dtype=np.int64) * 30, n_aids=n_aids)
+    for kinds in (('click_weighted', 'cart_weighted', 'order_weighted'), ('time_weighted', 'click_weighted')):
+        want = _oracle_rows(ev, kinds)
+        b, got = _build(ev, gpu_device, kinds=kinds, l_cap=l_cap)
+        assert b.stats()['items_l'] >= 58000 // (2 * l_cap)
+        _assert_rows_equal(got, want, kinds)
+
+
 @pytest.mark.parametrize('n_sess', [4095, 4096, 9000])
 def test_packed_heavy_layout_counter_limit(gpu_device, n_sess):
     """Heavy aids with fewer than 4096 runs use 12-bit packed counters (a pair gains at most one record per session
