@@ -43,8 +43,8 @@ __device__ __forceinline__ uint32_t wave_min_u(uint32_t v) {
 __global__ __launch_bounds__(256) void k_inter_rows(const uint32_t* aid, const uint8_t* type, const int64_t* off, int64_t n_sess,
                                                     const int32_t* cand, const float* score, int C, const int64_t* cand_off,
                                                     uint32_t n_aids, uint16_t* row, float* sess_feat, AidAcc* acc, uint32_t* err) {
-    __shared__ uint32_t s_aid[4][OTTO_INTER_MAX_SESSION];
-    __shared__ uint8_t s_type[4][OTTO_INTER_MAX_SESSION];
+    __shared__ __attribute__((aligned(16))) uint32_t s_aid[4][OTTO_INTER_MAX_SESSION];
+    __shared__ __attribute__((aligned(16))) uint8_t s_type[4][OTTO_INTER_MAX_SESSION];
     const int w = threadIdx.x >> 6;
     const unsigned lane = lane_id();
     const float nanf_ = __builtin_nanf("");
@@ -68,11 +68,19 @@ __global__ __launch_bounds__(256) void k_inter_rows(const uint32_t* aid, const u
             const int32_t y = c < Cs ? cand[cb + c] : -1;
             uint32_t cnt[3] = {0, 0, 0}, last = 0;
             if (y >= 0) {
-                for (int i = 0; i < n; ++i) {
-                    if (s_aid[w][i] == (uint32_t)y) {
-                        const uint32_t t = s_type[w][i];
-                        cnt[0] += t == 0; cnt[1] += t == 1; cnt[2] += t == 2;
-                        last = (uint32_t)i + 1u;                        // cumcount + 1 of the last occurrence (:57-65)
+                // four events per LDS read, no branch: a loop of one dependent LDS read + branch per event runs at one LDS
+                // round trip per event
+#pragma unroll 2
+                for (int i0 = 0; i0 < n; i0 += 4) {
+                    const uint4 a4 = *reinterpret_cast<const uint4*>(&s_aid[w][i0]);
+                    const uint32_t t4 = *reinterpret_cast<const uint32_t*>(&s_type[w][i0]);
+                    const uint32_t aj[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t t = (t4 >> (8 * e)) & 0xFFu;
+                        const uint32_t eq = (aj[e] == (uint32_t)y && i0 + e < n) ? 1u : 0u;
+                        cnt[0] += eq & (t == 0 ? 1u : 0u); cnt[1] += eq & (t == 1 ? 1u : 0u); cnt[2] += eq & (t == 2 ? 1u : 0u);
+                        last = eq ? (uint32_t)(i0 + e) + 1u : last;        // cumcount + 1 of the last occurrence (:57-65)
                     }
                 }
                 const uint32_t occ = cnt[0] + cnt[1] + cnt[2];
