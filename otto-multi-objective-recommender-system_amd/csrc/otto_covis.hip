@@ -3099,9 +3099,11 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
 #endif
 }
 
-// merge the R partial top-k lists of one heavy aid (item with part == 0 and R > 1): one wave per item
+// merge the R partial top-k lists of one heavy aid (item with part == 0 and R > 1): one workgroup per item, ONE WAVE PER KIND
+// (the largest aid's 5,000 - 10,000 candidates per kind are one wave's serial work: the kernel lasts as long as that aid),
+// the next 64 candidates requested before the current ones are merged
 template <int GROUP>
-__global__ __launch_bounds__(64) void k_merge(ReduceArgs a) {
+__global__ __launch_bounds__(64 * PK) void k_merge(ReduceArgs a) {
     using K = typename std::conditional<GROUP == OTTO_COVIS_GROUP_TIME, KeyW, KeyN>::type;
     const uint32_t it = blockIdx.x;
     if (it >= a.n_items) return;
@@ -3112,26 +3114,35 @@ __global__ __launch_bounds__(64) void k_merge(ReduceArgs a) {
     const uint32_t x = (uint32_t)(item & REC_AID_MASK);
     if (a.flag[x]) return;
     const unsigned lane = lane_id();
+    const int j = (int)(threadIdx.x >> 6);
+    if (j >= a.nk) return;
     const uint64_t ncand = (uint64_t)a.k << lgR;
-    for (int j = 0; j < a.nk; ++j) {
-        K best;
-        kclear(best);
-        for (uint64_t c0 = 0; c0 < ncand; c0 += 64) {
-            const uint64_t c = c0 + lane;
-            K cand;
-            kclear(cand);
-            if (c < ncand) {
-                const size_t o = ((size_t)(it + c / a.k) * a.nk + j) * (size_t)a.k + (c % a.k);
-                kload(cand, a.part_w[o], a.part_y[o]);
-            }
-            wave_topk_push(best, cand, a.k);
+    auto fetch = [&](uint64_t c0) {
+        const uint64_t c = c0 + lane;
+        K cand;
+        kclear(cand);
+        if (c < ncand) {
+            const size_t o = ((size_t)(it + c / a.k) * a.nk + j) * (size_t)a.k + (c % a.k);
+            kload(cand, a.part_w[o], a.part_y[o]);
         }
-        const bool valid = (int)lane < a.k && kvalid(best);
-        const size_t o = ((size_t)(a.kind_base + j) * a.n_aids + x) * (size_t)a.k + lane;
-        if (valid) { a.out_y[o] = kaid(best); a.out_w[o] = kweight(best); }
-        const int nvalid = __popcll(__ballot(valid));
-        if (lane == 0) a.out_n[(size_t)(a.kind_base + j) * a.n_aids + x] = nvalid;
+        return cand;
+    };
+    K best;
+    kclear(best);
+    K cand = fetch(0);
+    for (uint64_t c0 = 0; c0 < ncand; c0 += 64) {
+        const K nxt = c0 + 64 < ncand ? fetch(c0 + 64) : cand;
+        // the first 64 candidates are sorted at once (into an empty list every one of them would be pushed one by one: 64
+        // serial insertions per kind and aid); later batches push the few that beat the k-th
+        if (c0 == 0) { best = cand; wave_bitonic_sort_desc(best); }
+        else wave_topk_push(best, cand, a.k);
+        cand = nxt;
     }
+    const bool valid = (int)lane < a.k && kvalid(best);
+    const size_t o = ((size_t)(a.kind_base + j) * a.n_aids + x) * (size_t)a.k + lane;
+    if (valid) { a.out_y[o] = kaid(best); a.out_w[o] = kweight(best); }
+    const int nvalid = __popcll(__ballot(valid));
+    if (lane == 0) a.out_n[(size_t)(a.kind_base + j) * a.n_aids + x] = nvalid;
 }
 
 // ---------------------------------------------------------------------------
@@ -3984,7 +3995,7 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
         OTTO_HIP(hipGetLastError());
         tbegin(c, OTTO_COVIS_T_MERGE, s);
         kname(c, OTTO_COVIS_T_MERGE, "k_merge<%d>", GROUP);
-        k_merge<GROUP><<<a.n_items, 64, 0, s>>>(a);
+        k_merge<GROUP><<<a.n_items, 64 * PK, 0, s>>>(a);
         tend(c, OTTO_COVIS_T_MERGE, s);
     }
     OTTO_HIP(hipGetLastError());
