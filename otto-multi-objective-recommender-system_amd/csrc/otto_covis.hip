@@ -1939,7 +1939,9 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     using K = typename std::conditional<GROUP == OTTO_COVIS_GROUP_TIME, KeyW, KeyN>::type;
     constexpr bool WIDE = GROUP == OTTO_COVIS_GROUP_TIME;
     static_assert(!(PACKED && WIDE), "the time group needs the wide table layout");
-    constexpr bool DYNAMIC = THREADS != S_THREADS;   // work items dequeued with an atomic counter
+    // work items dequeued with an atomic counter. The one-wave bin too (round 3): with a static stride a workgroup's ~220 aids of
+    // 1 .. 256 records add up to sums that differ by +-25 % across the 5,120 workgroups, and the kernel lasts as long as the unluckiest
+    constexpr bool DYNAMIC = true;
     constexpr int EXCAP = 64;
     constexpr int PKD = WIDE ? 1 : PK;      // the time-weighted group has a single kind
     // BOUND (type-weighted group): the kinds of a pass are linear in the same three counters with per-type coefficients
@@ -2008,7 +2010,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     uint32_t idx_next = 0, idx_far = 0;   // DYNAMIC, thread 0: dequeued indices of the next two items
     // Items are reserved DQ at a time (same-address atomics retire at ~90 M/s: one per item would cost 5 ms for the M
     // bin alone); the next chunk is requested when the current one is opened, so its latency is never waited for.
-    constexpr uint32_t DQ = 4;
+    constexpr uint32_t DQ = THREADS == S_THREADS ? 16 : 4;      // (1.1 M one-wave items: 70 k counter bumps)
     uint32_t pool = 0, pool_end = 0, pool_next = 0;
     auto take = [&]() {
         const uint32_t r = pool++;
