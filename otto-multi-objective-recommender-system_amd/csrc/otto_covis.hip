@@ -1537,6 +1537,7 @@ struct PartArgs {
     int allow_packed;
     uint32_t* flag;                // [n_aids] bucket overflow (capacity-sized buckets): the aid is redone with exact bucket sizes
     uint32_t* ovf_count;
+    uint32_t* work;                // scatter pass: chunk dequeue counter (zeroed before the launch)
 };
 
 // Capacity of a partition bucket when the buckets are sized WITHOUT the count pass: twice the mean partition size + a
@@ -1651,17 +1652,39 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
             const uint64_t mine = k.rb + (uint64_t)lane * NW + wid;
             return mine < k.re ? a.sorted_desc[mine] : 0ull;
         };
-        const uint64_t G = gridDim.x;
-        uint64_t ci = blockIdx.x;
+        // chunks are dequeued dynamically, CQ per counter bump (thread 0; the index three chunks ahead is published through LDS
+        // and read after the barriers of the chunk in between): a static deal left the workgroups' sums uneven
+        __shared__ uint32_t s_ci[4];
+        constexpr uint32_t CQ = 4;
+        uint32_t pool = 0, pool_end = 0, pool_next = 0;
+        auto take = [&]() {
+            const uint32_t r = pool++;
+            if (pool == pool_end) {
+                pool = pool_next;
+                pool_end = pool + CQ;
+                pool_next = atomicAdd(a.work, CQ);
+            }
+            return r;
+        };
+        if (threadIdx.x == 0) {
+            pool = atomicAdd(a.work, 2 * CQ);
+            pool_end = pool + CQ;
+            pool_next = pool + CQ;
+            s_ci[2] = take(); s_ci[3] = take(); s_ci[0] = take();
+        }
+        __syncthreads();
+        uint64_t ci = s_ci[2], ci1 = s_ci[3], ci2 = s_ci[0];
+        __syncthreads();
         if (ci >= a.n_chunks) return;
         uint64_t ch_cur = uni64(ld_chunk(ci));
-        uint64_t ch_nxt_v = ld_chunk(ci + G);
+        uint64_t ch_nxt_v = ld_chunk(ci1);
         Chunk cur = mk(ch_cur, ld_aid(ch_cur));
         uint64_t xb_cur_v = a.pstart[cur.g0 + vz];
         uint64_t d_cur = ld_desc(cur);
-        for (; ci < a.n_chunks; ci += G) {
+        for (uint32_t it = 0; ci < a.n_chunks; ++it) {
+            if (threadIdx.x == 0) s_ci[it & 1u] = take();   // the chunk after ci2: read at the end of this iteration
             const uint64_t ch_nxt = uni64(ch_nxt_v);     // requested one chunk ago
-            const uint64_t ch_n2_v = ld_chunk(ci + 2 * G);
+            const uint64_t ch_n2_v = ld_chunk(ci2);
             const Aid aid_nxt = ld_aid(ch_nxt);          // lands while this chunk's records are gathered
             Chunk nxt{};
             uint64_t xb_nxt_v = 0, d_nxt = 0;
@@ -1729,8 +1752,9 @@ __global__ __launch_bounds__(256) void k_partition(PartArgs a) {
                         if (TW) a.ptw[o] = s_stage_tw[(SCATTER && TW) ? si : 0];
                     }
                 }
-                __syncthreads();
             }
+            __syncthreads();
+            ci = ci1; ci1 = ci2; ci2 = s_ci[it & 1u];
             cur = nxt;
             xb_cur_v = xb_nxt_v;
             d_cur = d_nxt;
@@ -3395,8 +3419,8 @@ struct otto_covis_ctx {
     DevBuf bcount, bstart, tmp_runs;          // bucketed index
     int bucket_index = 1;          // option "bucket_index": LDS-atomic index build (0 = global-atomic histogram)
     int s_wgs = 20;                // option "s_wgs": one-wave workgroups of the S bin per CU (A/B)
-    int p_wgs = 12;                // option "p_wgs": workgroups of the partition scatter per CU. 4 are resident (38 KB of LDS each); chunks are dealt
-                                   // statically, so 3 rounds of workgroups even out the chunk sizes (sweep 3 .. 64 in profiles/round3/partition_pipeline_ab.log)
+    int p_wgs = 4;                 // option "p_wgs": workgroups of the partition scatter per CU (4 are resident: 38 KB of LDS each; chunks are dequeued
+                                   // dynamically, so the count no longer matters: 4 / 8 / 12 measure 2.92 ms; the static deal needed 12 for 2.99)
     int bkt_sh = 0;                // option "bkt_sh": log2 aids per index bucket (0 = from the aid space)
     DevBuf lorder[3][3], lrank, lmode_start;   // [bin][mode] processing order of the tiers / layouts (heavy: pilots first)
     uint64_t n_order[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -3877,7 +3901,7 @@ static int run_partition(otto_covis_ctx* c, const ReduceArgs& a, bool time, hipS
                 c->pstart.as<uint64_t>(), nullptr, nullptr, c->l_cap, c->p.window, a.allow_packed, c->flag.as<uint32_t>(),
                 c->counters.as<uint32_t>()};
     const uint32_t pres = 256u * (uint32_t)c->p_wgs;
-    const uint32_t pgrid = (uint32_t)(c->n_chunks < pres ? c->n_chunks : pres);   // chunks are dealt statically
+    const uint32_t pgrid = (uint32_t)(c->n_chunks < pres ? c->n_chunks : pres);
     const uint32_t cgrid = (uint32_t)(c->n_chunks < 256u * 8u ? c->n_chunks : 256u * 8u);
     // First attempt: buckets sized from the record counts the index already holds (2 x mean + margin), no count pass.
     // Retry rounds (aids whose bucket or LDS table overflowed): counted buckets, exact.
@@ -3899,6 +3923,8 @@ static int run_partition(otto_covis_ctx* c, const ReduceArgs& a, bool time, hipS
     if (time) OTTO_TRY(c->ptw.ensure((size_t)(bucket_total ? bucket_total : 1) * 4, 0, s));
     pa.prec = c->prec.as<uint32_t>();
     pa.ptw = time ? c->ptw.as<uint32_t>() : nullptr;
+    pa.work = c->counters.as<uint32_t>() + 8;             // (slots 0 .. 3: overflow count + the reduce bins' work counters)
+    OTTO_HIP(hipMemsetAsync(pa.work, 0, 4, s));
     if (time) k_partition<true, true><<<pgrid, 256, 0, s>>>(pa);
     else k_partition<true, false><<<pgrid, 256, 0, s>>>(pa);
     OTTO_HIP(hipGetLastError());
