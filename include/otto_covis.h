@@ -127,7 +127,7 @@ int otto_covis_stats(otto_covis_ctx* ctx, int64_t* out /* [OTTO_COVIS_STAT_COUNT
  *   "hot": 2 (default) top-k walks over the heavy keys only + single-wave selection where they are few, 1 walks only, 0 off;
  *   "bkt_sh": log2 of the aids per index bucket (default clamp(aid_bits - 10, 10, 13)); "part_sized": 1 (default) partition buckets
  *            sized from the record counts without a count pass; "overlap_partition": 1 partition pass on a side stream beside the
- *            S / M bins (default 0); "s_wgs" / "p_wgs": workgroups per CU of the one-wave reduce bin (20) / the partition scatter (12);
+ *            S / M bins (default 0); "s_wgs" / "p_wgs": workgroups per CU of the one-wave reduce bin (20) / the partition scatter (4; its chunks are dequeued dynamically);
  *   "debug_skip": timing diagnostics only (results invalid): 1 no gather, 2 no top-k, 4 no table clear, 8 no inserts,
  *                 16 / 32 pair-expand without record stores / row loops. */
 int otto_covis_set_option(otto_covis_ctx* ctx, const char* name, int64_t value);
