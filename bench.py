@@ -252,7 +252,7 @@ def next_rows_leg(data, dev, n_aids, cand_sessions=1_800_000):
     return res
 
 
-def dropin_leg(data, dev, n_aids, ts_min, ts_max, k, reps=2):
+def dropin_leg(data, dev, n_aids, ts_min, ts_max, k, reps=3):
     """What `covisitation/builder.py <mode>` runs on the device for the reference's consumers: the 7 matrix kinds
     (time_weighted, three type-weighted, three filter kinds) of one event stream, top-k each: class-sorted pair-expand
     (filter kinds), time channel, three reduce groups. Device-resident inputs, like the headline value."""
@@ -268,13 +268,15 @@ def dropin_leg(data, dev, n_aids, ts_min, ts_max, k, reps=2):
         return b.finalize(k=k)
     step()
     torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
+    each = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         step()
-    torch.cuda.synchronize(dev)
-    ms = 1e3 * (time.perf_counter() - t0) / reps
+        torch.cuda.synchronize(dev)
+        each.append(1e3 * (time.perf_counter() - t0))
+    ms = sum(each) / len(each)
     st = b.stats()
-    return {'ms_per_build': round(ms, 2), 'aid_pairs_per_s': round(st['pairs'] / (ms * 1e-3), 1), 'kinds': list(REFERENCE_KINDS), 'k': k,
+    return {'ms_per_build': round(ms, 2), 'ms_each_build': [round(v, 2) for v in each], 'aid_pairs_per_s': round(st['pairs'] / (ms * 1e-3), 1), 'kinds': list(REFERENCE_KINDS), 'k': k,
             'note': 'pairs counted once (the all-ones expansion feeds every kind); kernel_ms of the last reduce group below',
             'kernel_ms_last_group': {n: round(v, 3) for n, v in b.timings().items()}, 'kernels': b.kernel_names()}
 
