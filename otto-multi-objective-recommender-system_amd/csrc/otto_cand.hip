@@ -98,7 +98,9 @@ __global__ __launch_bounds__(256) void k_cand_classify(const int64_t* sess_off, 
 // Two instantiations share the code: <32, 10, 128> for short sessions (16 KB of LDS: ten workgroups per CU instead of
 // two -- most sessions are short and the per-session phases are barrier / latency bound) and <500, 12, 256> for the rest.
 template <int CD_MAXL, int CD_LOG2T, int CD_THREADS>
-__global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(CandArgs a) {
+// (launch bounds: 5 waves per SIMD for the short variant = ten 2-wave workgroups per CU; 4 for the long one = TWO 8-wave workgroups
+// per CU, which its 78 KB of LDS allow -- without the bound the compiler took 168 registers and one workgroup fit)
+__global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 4) void k_cand(CandArgs a) {
     constexpr int CD_NW = CD_THREADS / 64;
     constexpr int CD_T = 1 << CD_LOG2T;
     constexpr int CD_CAP = CD_T / 4 * 3;                 // list entries per hash partition (load <= 3/4)
@@ -114,11 +116,15 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
     __shared__ unsigned long long s_tab[CD_T];        // aid << 32 | count
     __shared__ uint32_t s_fp[CD_T];                    // first position
     __shared__ uint64_t s_sel[OTTO_CAND_MAX_COMMON];   // running most_common list (sorted)
-    __shared__ uint64_t s_lb[CD_THREADS];
-    __shared__ uint64_t s_ex[OTTO_CAND_MAX_COMMON];
+    // one pool for three arrays that are never live together: the gather's segment table (CD_NW x 256 bytes), the radix-select
+    // histogram (256 or 1024 bins) and the compacted selection (OTTO_CAND_MAX_COMMON keys). Short-session variant: 16.3 instead of
+    // 17.8 KB of LDS = ten workgroups per CU instead of nine (the kernel scales with its resident waves).
+    constexpr int CD_POOL = (CD_THREADS * 8 >= 4096 ? 4096 : 1024) > CD_NW * 256 ? (CD_THREADS * 8 >= 4096 ? 4096 : 1024) : CD_NW * 256;
+    __shared__ __attribute__((aligned(16))) uint8_t s_pool[CD_POOL > OTTO_CAND_MAX_COMMON * 8 ? CD_POOL : OTTO_CAND_MAX_COMMON * 8];
+    uint64_t* s_ex = reinterpret_cast<uint64_t*>(s_pool);
     __shared__ uint32_t s_nex, s_more, s_ovf, s_nfresh, s_sp, s_scan[CD_NW + 1], s_keep[2], s_maxlen;
     __shared__ uint32_t s_stack[CD_STACK];            // hash partitions still to do: id | level << 24
-    __shared__ uint8_t s_seg[CD_NW * 256];            // gather: segment -> list lane << 2 | segment of the list, per wave
+    uint8_t* s_seg = s_pool;                          // gather: segment -> list lane << 2 | segment of the list, per wave
 
     const int tid = threadIdx.x, wid = tid >> 6;
     const unsigned lane = lane_id();
@@ -502,11 +508,11 @@ __global__ __launch_bounds__(CD_THREADS, CD_THREADS == 128 ? 5 : 1) void k_cand(
                     ck[q] = c;
                     ok[q] = c ? (((c >> 50) << TB) | (((c >> 26) & 0xFFFFFFull) - fpb)) : 0ull;
                 }
-                // digits of DB bits: 10 where the histogram fits (512 threads: s_lb is 4 KB), 8 otherwise -- two passes instead of
+                // digits of DB bits: 10 where the histogram fits (512 threads: a 4 KB pool), 8 otherwise -- two passes instead of
                 // three for the long sessions (count < 2^8, TOT < 2^12)
                 constexpr int DB = CD_THREADS * 8 >= 4096 ? 10 : 8;
                 constexpr int NBIN = 1 << DB, BPL = NBIN / 64;         // bins, bins per lane of the scanning wave
-                uint32_t* hist = reinterpret_cast<uint32_t*>(s_lb);   // NBIN bins (s_lb: CD_THREADS x 8 bytes)
+                uint32_t* hist = reinterpret_cast<uint32_t*>(s_pool); // NBIN bins
                 for (int i = tid; i < NBIN; i += CD_THREADS) hist[i] = 0;
                 if (tid == 0) s_nex = 0;
                 // a key occurs at most once per list: count <= Q
