@@ -75,7 +75,8 @@ def write_part(job):
     import pyarrow as pa
     import pyarrow.parquet as pq
     path, aid_x, aid_y, W = job
-    pq.write_table(pa.table({'aid_x': aid_x.astype(np.int32), 'aid_y': aid_y.astype(np.int32),
+    i32 = lambda a: a.view(np.int32) if a.dtype == np.uint32 and a.flags.c_contiguous else a.astype(np.int32)   # aids < 2^26: a view, not a copy
+    pq.write_table(pa.table({'aid_x': i32(aid_x), 'aid_y': i32(aid_y),
                              'wgt': (W.astype(np.float64) / Q16).astype(np.float32)}), path)
 
 
