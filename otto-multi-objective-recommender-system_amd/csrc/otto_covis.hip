@@ -1960,14 +1960,19 @@ template <int LOG2T, int THREADS, int GROUP, bool PACKED, int MINW, int GU, int 
 __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     constexpr int T = 1 << LOG2T;
     constexpr int NW = THREADS / 64;
-    using K = typename std::conditional<GROUP == OTTO_COVIS_GROUP_TIME, KeyW, KeyN>::type;
-    constexpr bool WIDE = GROUP == OTTO_COVIS_GROUP_TIME;
-    static_assert(!(PACKED && WIDE), "the time group needs the wide table layout");
+    // TP: the time-weighted kind in the packed layout (S / M bins). Its weight 65536 * count + sum of the Q16 time extras is ONE sum
+    // of (65536 + extra) per record, < 2^30 for an aid of <= 3072 records: the slot is aid_y << 36 | that sum, one LDS atomic per
+    // record instead of three, a 64-bit key, and the 40 KB table (four workgroups per CU) instead of 72 KB of wide counters (two).
+    constexpr bool TP = GROUP == OTTO_COVIS_GROUP_TIME && PACKED;
+    using K = typename std::conditional<GROUP == OTTO_COVIS_GROUP_TIME && !PACKED, KeyW, KeyN>::type;
+    constexpr bool WIDE = GROUP == OTTO_COVIS_GROUP_TIME && !PACKED;
+    static_assert(!TP || LOG2T <= M_LOG2T, "the packed time sum holds the records of an S / M aid only");
+    auto kw = [](K key) -> uint64_t { if constexpr (TP) return key.c >> REC_AID_BITS; else return kweight(key); };   // Q16 weight of a key
     // work items dequeued with an atomic counter. The one-wave bin too (round 3): with a static stride a workgroup's ~220 aids of
     // 1 .. 256 records add up to sums that differ by +-25 % across the 5,120 workgroups, and the kernel lasts as long as the unluckiest
     constexpr bool DYNAMIC = true;
     constexpr int EXCAP = 64;
-    constexpr int PKD = WIDE ? 1 : PK;      // the time-weighted group has a single kind
+    constexpr int PKD = GROUP == OTTO_COVIS_GROUP_TIME ? 1 : PK;      // the time-weighted group has a single kind
     // BOUND (type-weighted group): the kinds of a pass are linear in the same three counters with per-type coefficients
     // between lo[t] = min_j coef[j][t] and hi[t] = max_j coef[j][t], so ONE lower-bound key KL and ONE upper-bound key KH
     // per table slot bracket the key of every kind: KL <= key_j <= KH. With lambda <= the k-th largest KL, every kind's
@@ -2203,9 +2208,11 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 if (fb & 4u) atomicAdd(&s_v[2][PACKED ? 0 : found], 1u);
             }
         };
-        auto packed_add = [&](uint32_t rc) -> unsigned long long {
+        auto packed_add = [&](uint32_t rc, uint32_t e) -> unsigned long long {
             uint32_t add0, add1, add2;
-            if (GROUP == OTTO_COVIS_GROUP_TYPE) {
+            if (GROUP == OTTO_COVIS_GROUP_TIME) {
+                return 65536ull + (unsigned long long)e;
+            } else if (GROUP == OTTO_COVIS_GROUP_TYPE) {
                 const uint32_t tyj = (rc >> REC_AID_BITS) & 3u;              // counter tyj: bit 12 * tyj (type 3 does not occur: 36 & 31 = 4 is masked off)
                 return (unsigned long long)((1u << ((tyj * 12u) & 31u)) & 0x01001001u);
             } else {
@@ -2248,7 +2255,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                         const uint32_t r = rc[c0 + q < N ? c0 + q : 0];
                         const uint32_t slot = rec_hash(r) >> (32 - LOG2T);
                         oldhi[q] = 0xFFFFFFFFu;
-                        addq[q] = packed_add(r);
+                        addq[q] = packed_add(r, e[c0 + q < N ? c0 + q : 0]);
                         if (ok[q]) {
                             const unsigned long long o = atomicCAS((unsigned long long*)&s_tab[PACKED ? slot : 0], (unsigned long long)TAB_EMPTY,
                                                                    ((unsigned long long)(r & REC_AID_MASK) << 36) | addq[q]);
@@ -2316,7 +2323,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             for (int j = 0; j < PKD; ++j) {
                 uint64_t uw = 0, qw = 0;
                 if (y != KEY_EMPTY) {
-                    if (GROUP == OTTO_COVIS_GROUP_TIME) qw = 65536ull * v0 + (((uint64_t)v2 << 32) | v1);
+                    if (TP) uw = (uint64_t)v0 | ((uint64_t)v1 << 12) | ((uint64_t)v2 << 24);
+                    else if (GROUP == OTTO_COVIS_GROUP_TIME) qw = 65536ull * v0 + (((uint64_t)v2 << 32) | v1);
                     else if (PACKED) uw = __umul24(v0, a.coef[j][0]) + __umul24(v1, a.coef[j][1]) + __umul24(v2, a.coef[j][2]);   // 12-bit counts x 8-bit weights: v_mad_u32_u24 (v_mul_lo_u32 is quarter rate)
                     else uw = (uint64_t)v0 * a.coef[j][0] + (uint64_t)v1 * a.coef[j][1] + (uint64_t)v2 * a.coef[j][2];
                 }
@@ -2328,7 +2336,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
             const bool valid = (int)lane < a.k && kvalid(best);
             if (lgR == 0) {
                 const size_t o = ((size_t)(a.kind_base + j) * a.n_aids + x) * (size_t)a.k + lane;
-                if (valid) { a.out_y[o] = kaid(best); a.out_w[o] = kweight(best); }
+                if (valid) { a.out_y[o] = kaid(best); a.out_w[o] = kw(best); }
                 const int nvalid = __popcll(__ballot(valid));
                 if (lane == 0) a.out_n[(size_t)(a.kind_base + j) * a.n_aids + x] = nvalid;
             } else if ((int)lane < a.k) {
@@ -2438,7 +2446,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 const bool put = kvalid(key) && rank < (uint32_t)a.k;
                 if (lgR == 0) {
                     const size_t o = ((size_t)(a.kind_base + j) * a.n_aids + x) * (size_t)a.k + rank;
-                    if (put) { a.out_y[o] = kaid(key); a.out_w[o] = kweight(key); }
+                    if (put) { a.out_y[o] = kaid(key); a.out_w[o] = kw(key); }
                     if (lane == 0) a.out_n[(size_t)(a.kind_base + j) * a.n_aids + x] = nv < a.k ? nv : a.k;
                 } else {
                     const size_t base = ((size_t)it * a.nk + j) * (size_t)a.k;
@@ -2782,7 +2790,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 }
                 uint64_t uw = 0, qw = 0;
                 if (y != KEY_EMPTY) {
-                    if (GROUP == OTTO_COVIS_GROUP_TIME) qw = 65536ull * v0 + (((uint64_t)v2 << 32) | v1);
+                    if (TP) uw = (uint64_t)v0 | ((uint64_t)v1 << 12) | ((uint64_t)v2 << 24);
+                    else if (GROUP == OTTO_COVIS_GROUP_TIME) qw = 65536ull * v0 + (((uint64_t)v2 << 32) | v1);
                     else if (PACKED) uw = __umul24(v0, c0) + __umul24(v1, c1) + __umul24(v2, c2);
                     else uw = (uint64_t)v0 * c0 + (uint64_t)v1 * c1 + (uint64_t)v2 * c2;
                 }
@@ -2795,7 +2804,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
                 const bool put = kvalid(key) && rank < (uint32_t)a.k;
                 if (lgR == 0) {
                     const size_t o = ((size_t)(a.kind_base + j) * a.n_aids + x) * (size_t)a.k + rank;
-                    if (put) { a.out_y[o] = kaid(key); a.out_w[o] = kweight(key); }
+                    if (put) { a.out_y[o] = kaid(key); a.out_w[o] = kw(key); }
                     if (lane == 0) a.out_n[(size_t)(a.kind_base + j) * a.n_aids + x] = nv < a.k ? nv : a.k;
                 } else {
                     const size_t base = ((size_t)it * a.nk + j) * (size_t)a.k;
@@ -3968,14 +3977,14 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
         uint32_t grid = a.n_items < s_res ? a.n_items : s_res;
         tbegin(c, OTTO_COVIS_T_REDUCE_S, s);
         prof_begin();
-        OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_S, grid, S_THREADS, a, S_LOG2T, S_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, 5, 4);
+        OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_S, grid, S_THREADS, a, S_LOG2T, S_THREADS, GROUP, true, 5, 4);
         prof_end("S", a.n_work);
         tend(c, OTTO_COVIS_T_REDUCE_S, s);
     } else if (bin == 1) {
         uint32_t grid = a.n_items < 256u * 4u ? a.n_items : 256u * 4u;
         tbegin(c, OTTO_COVIS_T_REDUCE_M, s);
         prof_begin();
-        OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_M, grid, M_THREADS, a, M_LOG2T, M_THREADS, GROUP, GROUP != OTTO_COVIS_GROUP_TIME, (GROUP != OTTO_COVIS_GROUP_TIME ? 4 : 2), 4);
+        OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_M, grid, M_THREADS, a, M_LOG2T, M_THREADS, GROUP, true, 4, 4);
         prof_end("M", a.n_work);
         tend(c, OTTO_COVIS_T_REDUCE_M, s);
     } else {
