@@ -1960,13 +1960,14 @@ template <int LOG2T, int THREADS, int GROUP, bool PACKED, int MINW, int GU, int 
 __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
     constexpr int T = 1 << LOG2T;
     constexpr int NW = THREADS / 64;
-    // TP: the time-weighted kind in the packed layout (S / M bins). Its weight 65536 * count + sum of the Q16 time extras is ONE sum
-    // of (65536 + extra) per record, < 2^30 for an aid of <= 3072 records: the slot is aid_y << 36 | that sum, one LDS atomic per
+    // TP: the time-weighted kind in the packed layout. Its weight 65536 * count + sum of the Q16 time extras is ONE sum
+    // of (65536 + extra) per record, < 2^30 for the keys of an S / M aid (<= 3072 records) and of a packed-layout heavy aid: the slot is aid_y << 36 | that sum, one LDS atomic per
     // record instead of three, a 64-bit key, and the 40 KB table (four workgroups per CU) instead of 72 KB of wide counters (two).
     constexpr bool TP = GROUP == OTTO_COVIS_GROUP_TIME && PACKED;
     using K = typename std::conditional<GROUP == OTTO_COVIS_GROUP_TIME && !PACKED, KeyW, KeyN>::type;
     constexpr bool WIDE = GROUP == OTTO_COVIS_GROUP_TIME && !PACKED;
-    static_assert(!TP || LOG2T <= M_LOG2T, "the packed time sum holds the records of an S / M aid only");
+    // (TP in the heavy bin: only the packed layouts' aids, fewer than PACKED_MAX_RUNS = 4096 runs -- a key gains at most one record per
+    // run of x, so its sum stays below 4096 * 2^18 = 2^30)
     auto kw = [](K key) -> uint64_t { if constexpr (TP) return key.c >> REC_AID_BITS; else return kweight(key); };   // Q16 weight of a key
     // work items dequeued with an atomic counter. The one-wave bin too (round 3): with a static stride a workgroup's ~220 aids of
     // 1 .. 256 records add up to sums that differ by +-25 % across the 5,120 workgroups, and the kernel lasts as long as the unluckiest
@@ -3137,20 +3138,8 @@ __global__ __launch_bounds__(THREADS, MINW) void k_reduce(ReduceArgs a) {
 // merge the R partial top-k lists of one heavy aid (item with part == 0 and R > 1): one workgroup per item, ONE WAVE PER KIND
 // (the largest aid's 5,000 - 10,000 candidates per kind are one wave's serial work: the kernel lasts as long as that aid),
 // the next 64 candidates requested before the current ones are merged
-template <int GROUP>
-__global__ __launch_bounds__(64 * PK) void k_merge(ReduceArgs a) {
-    using K = typename std::conditional<GROUP == OTTO_COVIS_GROUP_TIME, KeyW, KeyN>::type;
-    const uint32_t it = blockIdx.x;
-    if (it >= a.n_items) return;
-    const uint64_t item = a.items[it];
-    const uint32_t part = (uint32_t)((item >> 26) & 0xFFFFFFu);
-    const int lgR = (int)(item >> 50);
-    if (part != 0 || lgR == 0) return;
-    const uint32_t x = (uint32_t)(item & REC_AID_MASK);
-    if (a.flag[x]) return;
-    const unsigned lane = lane_id();
-    const int j = (int)(threadIdx.x >> 6);
-    if (j >= a.nk) return;
+template <typename K, bool RAW>
+__device__ __forceinline__ void merge_lists(const ReduceArgs& a, uint32_t it, uint32_t x, int lgR, int j, unsigned lane) {
     const uint64_t ncand = (uint64_t)a.k << lgR;
     auto fetch = [&](uint64_t c0) {
         const uint64_t c = c0 + lane;
@@ -3175,9 +3164,35 @@ __global__ __launch_bounds__(64 * PK) void k_merge(ReduceArgs a) {
     }
     const bool valid = (int)lane < a.k && kvalid(best);
     const size_t o = ((size_t)(a.kind_base + j) * a.n_aids + x) * (size_t)a.k + lane;
-    if (valid) { a.out_y[o] = kaid(best); a.out_w[o] = kweight(best); }
+    if (valid) {
+        a.out_y[o] = kaid(best);
+        if constexpr (RAW) a.out_w[o] = best.c >> REC_AID_BITS;      // packed time-weighted keys carry the Q16 weight itself
+        else a.out_w[o] = kweight(best);
+    }
     const int nvalid = __popcll(__ballot(valid));
     if (lane == 0) a.out_n[(size_t)(a.kind_base + j) * a.n_aids + x] = nvalid;
+}
+
+template <int GROUP>
+__global__ __launch_bounds__(64 * PK) void k_merge(ReduceArgs a) {
+    const uint32_t it = blockIdx.x;
+    if (it >= a.n_items) return;
+    const uint64_t item = a.items[it];
+    const uint32_t part = (uint32_t)((item >> 26) & 0xFFFFFFu);
+    const int lgR = (int)(item >> 50);
+    if (part != 0 || lgR == 0) return;
+    const uint32_t x = (uint32_t)(item & REC_AID_MASK);
+    if (a.flag[x]) return;
+    const unsigned lane = lane_id();
+    const int j = (int)(threadIdx.x >> 6);
+    if (j >= a.nk) return;
+    if constexpr (GROUP == OTTO_COVIS_GROUP_TIME) {
+        // the aid's partitions wrote 64-bit packed keys (packed layouts) or wide (weight, aid) keys (wide layout)
+        if (heavy_mode(a.cnt64[x], a.allow_packed, a.l_cap) != 0) merge_lists<KeyN, true>(a, it, x, lgR, j, lane);
+        else merge_lists<KeyW, false>(a, it, x, lgR, j, lane);
+    } else {
+        merge_lists<KeyN, false>(a, it, x, lgR, j, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -4012,15 +4027,11 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
             OTTO_HIP(hipMemsetAsync(wc, 0, 4, s));
             prof_begin();
             if (mode == 2) {
-                if constexpr (GROUP != OTTO_COVIS_GROUP_TIME) {
-                    const uint32_t grid = am.n_work < 256u * 2u ? am.n_work : 256u * 2u;
-                    OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_L, grid, 512, am, L_LOG2T, 512, GROUP, true, 4, 4);
-                }
+                const uint32_t grid = am.n_work < 256u * 2u ? am.n_work : 256u * 2u;
+                OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_L, grid, 512, am, L_LOG2T, 512, GROUP, true, 4, 4);
             } else if (mode == 1) {
-                if constexpr (GROUP != OTTO_COVIS_GROUP_TIME) {
-                    const uint32_t grid = am.n_work < 256u ? am.n_work : 256u;
-                    OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_L, grid, L_THREADS, am, LP_LOG2T, L_THREADS, GROUP, true, 4, 2);
-                }
+                const uint32_t grid = am.n_work < 256u ? am.n_work : 256u;
+                OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_L, grid, L_THREADS, am, LP_LOG2T, L_THREADS, GROUP, true, 4, 2);
             } else {
                 const uint32_t grid = am.n_work < 256u ? am.n_work : 256u;
                 OTTO_LAUNCH_REDUCE(OTTO_COVIS_T_REDUCE_L, grid, L_THREADS, am, L_LOG2T, L_THREADS, GROUP, false, 4, 2);
@@ -4065,8 +4076,9 @@ extern "C" int otto_covis_finalize(otto_covis_ctx* c, int group, int k, uint32_t
     OTTO_REQUIRE(n_kinds > 0, "group %d has no kinds configured", group);
     hipStream_t s = (hipStream_t)stream;
     if (!c->index_valid) OTTO_TRY(build_index(c, s));
-    // the time group has no packed layout: its heavy aids are partitioned for the wide table
-    const int want_packed = (group != OTTO_COVIS_GROUP_TIME && c->packed_heavy) ? c->packed_heavy : 0;
+    // every group uses the same layout rule (the time-weighted kind has its packed form too: one sum per key, fewer than 4096 runs
+    // keep it under 2^30), so the heavy item list is built once for all groups
+    const int want_packed = c->packed_heavy ? c->packed_heavy : 0;
     if (c->items_allow_packed != want_packed) OTTO_TRY(build_items(c, 2, 0, s, want_packed));
     const uint32_t n_aids = p.n_aids;
     OTTO_HIP(hipMemsetAsync(d_out_n, 0, (size_t)n_kinds * n_aids * 4, s));
