@@ -3456,6 +3456,9 @@ struct otto_covis_ctx {
     hipStream_t side = nullptr;    // the partition pass of the heavy aids runs here, beside the S / M bins
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool part_early = false;       // the partition of this pass is in flight on `side`
+    uint64_t items_gen = 1;        // bumped whenever the heavy item list / partition chunks are rebuilt
+    uint64_t part_gen = 0;         // items_gen the partition buckets in prec / ptw were filled for (0: none)
+    bool part_has_tw = false;      // ... with the time channel alongside
     int overlap_partition = 0;     // option "overlap_partition": measured at full OTTO shape, both kernels take twice as long side by
                                    // side (partition 3.8 -> 6.2 ms, reduce S 2.9 -> 6.3 ms: the S bin's 20 workgroups per CU leave the
                                    // partition workgroups no LDS), the step gains 0.4 ms of 31.5 and the per-kernel times stop adding up:
@@ -3711,6 +3714,7 @@ extern "C" int otto_covis_feed(otto_covis_ctx* c, const uint32_t* d_aid, const i
 
 // pre (nullable): the totals of k_aid_totals for this configuration -- no host synchronisation then
 static int build_items(otto_covis_ctx* c, int bin, int only_flagged, hipStream_t s, int allow_packed = 0, const uint64_t* pre = nullptr) {
+    if (bin == 2) c->items_gen++;                        // the partition buckets of the previous list are stale
     const uint32_t n_aids = c->p.n_aids;
     ItemCount f{c->cnt64.as<uint64_t>(), c->boost.as<uint8_t>(), c->flag.as<uint32_t>(), bin, only_flagged, c->l_cap, allow_packed, -1};
     if (bin == 2) c->items_allow_packed = allow_packed;
@@ -3775,6 +3779,7 @@ static int build_items(otto_covis_ctx* c, int bin, int only_flagged, hipStream_t
 }
 
 static int build_index(otto_covis_ctx* c, hipStream_t s) {
+    c->items_gen++;                                      // new runs / a new heavy item list: the partition buckets are stale
     const uint32_t n_aids = c->p.n_aids;
     tbegin(c, OTTO_COVIS_T_INDEX, s);
     OTTO_TRY(c->cnt64.ensure((size_t)n_aids * 8, 0, s));
@@ -4009,8 +4014,15 @@ static int launch_reduce(otto_covis_ctx* c, ReduceArgs a, int bin, hipStream_t s
                 // launched on the side stream before the S / M bins (otto_covis_finalize): the heavy bin waits for it here
                 OTTO_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
                 c->part_early = false;
+                c->part_gen = 0;
+            } else if (c->part_gen == c->items_gen && !c->exact_round && (GROUP != OTTO_COVIS_GROUP_TIME || c->part_has_tw)) {
+                // the buckets of an earlier pass / group are still valid: every group partitions the same records of the same
+                // heavy item list the same way (a 7-kind build ran this pass three times)
             } else {
-                OTTO_TRY(run_partition(c, a, GROUP == OTTO_COVIS_GROUP_TIME, s));
+                const bool with_tw = c->p.want_time;          // once for every group: the time channel travels along if any group needs it
+                c->part_gen = 0;
+                OTTO_TRY(run_partition(c, a, with_tw, s));
+                if (!c->exact_round) { c->part_gen = c->items_gen; c->part_has_tw = with_tw; }
             }
             a.pstart = c->pstart.as<uint64_t>();
             a.pcursor = c->pcursor.as<uint32_t>();
@@ -4177,6 +4189,7 @@ extern "C" int otto_covis_finalize(otto_covis_ctx* c, int group, int k, uint32_t
 
 extern "C" int otto_covis_set_option(otto_covis_ctx* c, const char* name, int64_t value) {
     OTTO_REQUIRE(c && name, "null argument");
+    c->part_gen = 0;                                     // (any switch may change how the heavy aids are partitioned)
     if (strcmp(name, "l_cap") == 0) {
         // records per hash partition of a heavy aid (L bin). Larger = fewer passes over the aid's
         // records but more LDS-table overflows (each costs a re-partition round); any value is exact.
