@@ -234,6 +234,40 @@ def test_partition_scatter_paths_by_partition_count(gpu_device, l_cap):
         _assert_rows_equal(got, want, kinds)
 
 
+def test_context_reuse_across_streams_and_groups(gpu_device):
+    """One context, two different event streams one after the other (reset between them), kinds from all three reduce groups, hub
+    aids that are partitioned: the partition buckets are filled once per heavy item list and reused by the later passes and groups
+    -- they must not survive into the next stream's build, nor a second finalize with another k."""
+    from otto_amd.covisitation.engine import CovisBuilder, topk_to_rows
+    kinds = ('click_weighted', 'time_weighted', 'click_cart', 'cart_weighted')
+    rng = np.random.default_rng(31)
+
+    def hub_stream(S, n_aids, hub):
+        aid = rng.integers(1, n_aids, size=(S, 30)).astype(np.uint32)
+        aid[np.arange(S), rng.integers(0, 30, S)] = hub
+        ts = (1_660_000_000 + np.cumsum(rng.integers(1, 50, size=(S, 30)), axis=1)).astype(np.int32)
+        typ = rng.integers(0, 3, size=(S, 30)).astype(np.uint8)
+        return Events(aid=aid.ravel(), ts=ts.ravel(), type=typ.ravel(), sess_off=np.arange(S + 1, dtype=np.int64) * 30, n_aids=n_aids)
+    ev_a, ev_b = hub_stream(1500, 20000, 0), hub_stream(1100, 20000, 7)
+    ts_min = int(min(ev_a.ts.min(), ev_b.ts.min()))
+    ts_max = int(max(ev_a.ts.max(), ev_b.ts.max()))
+    b = CovisBuilder(20000, kinds=kinds, ts_min=ts_min, ts_max=ts_max, device=gpu_device)
+    b.set_option('l_cap', 512)
+    for ev, ks in ((ev_a, (20,)), (ev_b, (20, 15))):
+        b.reset()
+        b.feed(*_to_dev(ev, gpu_device))
+        fresh = CovisBuilder(20000, kinds=kinds, ts_min=ts_min, ts_max=ts_max, device=gpu_device)
+        fresh.set_option('l_cap', 512)
+        fresh.set_option('partition', 0)                  # a build that never uses the buckets
+        fresh.feed(*_to_dev(ev, gpu_device))
+        for k in ks:
+            out, ref = b.finalize(k=k), fresh.finalize(k=k)
+            assert b.stats()['items_l'] >= 2
+            got = {kind: topk_to_rows(*out[kind]) for kind in kinds}
+            want = {kind: topk_to_rows(*ref[kind]) for kind in kinds}
+            _assert_rows_equal(got, want, kinds)
+
+
 @pytest.mark.parametrize('n_sess', [4095, 4096, 9000])
 def test_packed_heavy_layout_counter_limit(gpu_device, n_sess):
     """Heavy aids with fewer than 4096 runs use 12-bit packed counters (a pair gains at most one record per session
