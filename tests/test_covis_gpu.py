@@ -640,7 +640,15 @@ def test_full_otto_bench_path_bit_exact_and_sampled_oracle(gpu_device, full_otto
     some = out1['click_weighted'][2] > 0
     assert bool((out1['cart_weighted'][1][:, 0] >= out1['click_weighted'][1][:, 0])[some].all())
 
-    # ---- sampled oracle ----
+    _sampled_oracle_check(d, dev, out1, BENCH_KINDS, k)
+
+
+def _sampled_oracle_check(d, dev, out, kinds, k, sizes=(100, 500, 1400), min_rows=15_000):
+    """~sum(sizes) `aid_x` stratified over the three size bins of the reduce (the five heaviest aids, sizes[0] of the heaviest 3 % ~ L
+    bin, sizes[1] of the next 26 % ~ M bin, sizes[2] of the rest ~ S bin). The row of `aid_x` depends only on the sessions that hold
+    `aid_x`, so the oracle run on exactly those sessions must reproduce the rows of the sampled aids exactly (aid_y, W and n)."""
+    import torch
+    from otto_amd.synth import OTTO_N_AIDS, OTTO_N_SESSIONS
     S, off, aid = OTTO_N_SESSIONS, d['sess_off'], d['aid'].long()
     E = aid.numel()
     L = off[1:] - off[:-1]
@@ -655,7 +663,7 @@ def test_full_otto_bench_path_bit_exact_and_sampled_oracle(gpu_device, full_otto
 
     def pick(lo, hi, m):
         return order[lo + torch.randperm(hi - lo, generator=g)[:m].to(dev)]
-    sample = torch.unique(torch.cat((order[:5], pick(5, b1, 100), pick(b1, b2, 500), pick(b2, n_pos, 1400))))
+    sample = torch.unique(torch.cat((order[:5], pick(5, b1, sizes[0]), pick(b1, b2, sizes[1]), pick(b2, n_pos, sizes[2]))))
     marked = torch.zeros(OTTO_N_AIDS, dtype=torch.bool, device=dev)
     marked[sample] = True
     sel = torch.zeros(S, dtype=torch.bool, device=dev)
@@ -664,30 +672,43 @@ def test_full_otto_bench_path_bit_exact_and_sampled_oracle(gpu_device, full_otto
     sub_off = np.r_[0, np.cumsum(L[sel].cpu().numpy())].astype(np.int64)
     sub_aid = d['aid'][ev_sel].cpu().numpy().astype(np.uint32)
     sub_ts, sub_typ = d['ts'][ev_sel].cpu().numpy(), d['type'][ev_sel].cpu().numpy()
-    assert 50_000 < len(sub_off) - 1 < 3_000_000, 'sample of sessions out of the intended range'
+    assert 20_000 < len(sub_off) - 1 < 3_000_000, 'sample of sessions out of the intended range'
     del sess, in_win, ev_sel, sel
     import covis_oracle_c as coc
     if coc.available():
-        want = coc.covis_topk_c(sub_aid, sub_ts, sub_typ, sub_off, OTTO_N_AIDS, BENCH_KINDS, k=k,
+        want = coc.covis_topk_c(sub_aid, sub_ts, sub_typ, sub_off, OTTO_N_AIDS, kinds, k=k,
                                 ts_min=d['ts_min'], ts_max=d['ts_max'])
     else:
         want = co.covis_topk_numpy(sub_aid, sub_ts, sub_typ, sub_off,
-                                   co.CovisSpec(kinds=BENCH_KINDS, ts_min=d['ts_min'], ts_max=d['ts_max']), k=k)
+                                   co.CovisSpec(kinds=kinds, ts_min=d['ts_min'], ts_max=d['ts_max']), k=k)
     smp = np.sort(sample.cpu().numpy())
     heavy = int(cnt.max())
     n_rows = 0
-    for kind in BENCH_KINDS:
+    for kind in kinds:
         wx, wy, ww = want[kind]
         keep = np.isin(wx, smp)
         wx, wy, ww = wx[keep], wy[keep], ww[keep]
-        y, w, n = (t[sample.sort().values].cpu().numpy() for t in out1[kind])
+        y, w, n = (t[sample.sort().values].cpu().numpy() for t in out[kind])
         valid = np.arange(k)[None, :] < n[:, None]
         gx = np.broadcast_to(smp[:, None], valid.shape)[valid].astype(np.uint32)
         assert len(gx) == len(wx), f'{kind}: {len(gx)} rows for the sampled aids vs oracle {len(wx)}'
         assert np.array_equal(gx, wx) and np.array_equal(y[valid].astype(np.uint32), wy), f'{kind}: sampled rows differ (aid)'
         assert np.array_equal(w[valid].astype(np.uint64), ww), f'{kind}: sampled rows differ (W)'
         n_rows += len(gx)
-    assert n_rows > 3 * 15_000 and heavy > 20_000, 'sample too thin to mean anything'
+    assert n_rows > len(kinds) * min_rows and heavy > 20_000, 'sample too thin to mean anything'
+
+
+
+def test_full_otto_time_weighted_sampled_oracle(gpu_device, full_otto):
+    """The time-weighted kind at full OTTO size through the default options: component-list pair-expand with the time channel
+    (`k_expand_lists<true>`), the partition pass carrying the extras, and the PACKED time sums of round 3 in all three bins (one sum of
+    65536 + extra per key: the heaviest aids' keys come closest to its 2^30 bound) -- against the oracle on ~900 sampled `aid_x`."""
+    from otto_amd.synth import OTTO_N_AIDS
+    d, dev, k = full_otto, gpu_device, 20
+    kinds = ('time_weighted',)
+    out, st = _full_run(d, dev, kinds, k, 1, {})
+    assert st['pairs'] > 1_000_000_000 and st['items_l'] > 0 and st['retries'] == 0
+    _sampled_oracle_check(d, dev, out, kinds, k, sizes=(60, 240, 600), min_rows=6_000)
 
 
 def test_full_otto_filter_kinds_properties(gpu_device, full_otto):
