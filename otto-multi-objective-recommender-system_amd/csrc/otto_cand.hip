@@ -762,10 +762,10 @@ struct RecencyArgs {
 // other first occurrences by (weight desc, first position asc) = Counter.most_common's stable order.
 template <int MAXL, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_recency(RecencyArgs a) {
-    __shared__ uint32_t s_aid[MAXL];
-    __shared__ double s_wc[OTTO_RECENCY_MAX_CURVES][MAXL];     // curve weight x type coefficient of event i
-    __shared__ double s_acc[OTTO_RECENCY_MAX_CURVES][MAXL];    // Counter value of the aid first seen at i
-    __shared__ uint8_t s_first[MAXL];
+    __shared__ __attribute__((aligned(16))) uint32_t s_aid[MAXL];
+    __shared__ __attribute__((aligned(16))) double s_wc[OTTO_RECENCY_MAX_CURVES][MAXL];     // curve weight x type coefficient of event i
+    __shared__ __attribute__((aligned(16))) double s_acc[OTTO_RECENCY_MAX_CURVES][MAXL];    // Counter value of the aid first seen at i
+    __shared__ __attribute__((aligned(16))) uint8_t s_first[MAXL];
     __shared__ uint32_t s_nu;
     const int tid = threadIdx.x;
     const int NCV = a.p.n_curves;
@@ -802,19 +802,35 @@ __global__ __launch_bounds__(THREADS) void k_recency(RecencyArgs a) {
             }
         }
         __syncthreads();
+        // The three session loops read FOUR events per LDS operation (one 16-byte read of aids / two of weights, one 4-byte read of
+        // flags): one dependent LDS read + branch per event ran at one LDS round trip per event.
         for (int i = tid; i < n; i += THREADS) {
             const uint32_t ai = s_aid[i];
-            bool first = true;
-            for (int j = 0; j < i; ++j) first = first && s_aid[j] != ai;
+            uint32_t seen = 0;
+#pragma unroll 2
+            for (int j0 = 0; j0 < i; j0 += 4) {
+                const uint4 a4 = *reinterpret_cast<const uint4*>(&s_aid[j0]);
+                seen |= (a4.x == ai ? 1u : 0u) | ((a4.y == ai && j0 + 1 < i) ? 1u : 0u) | ((a4.z == ai && j0 + 2 < i) ? 1u : 0u) |
+                        ((a4.w == ai && j0 + 3 < i) ? 1u : 0u);
+            }
+            const bool first = seen == 0;
             s_first[i] = first ? 1 : 0;
             if (first) {
                 atomicAdd(&s_nu, 1u);
-                for (int c = 0; c < NCV; ++c) {
-                    double acc = 0.0;
-                    for (int j = i; j < n; ++j)
-                        if (s_aid[j] == ai) acc = __dadd_rn(acc, s_wc[c][j]);
-                    s_acc[c][i] = acc;
+                double acc[OTTO_RECENCY_MAX_CURVES];
+#pragma unroll
+                for (int c = 0; c < OTTO_RECENCY_MAX_CURVES; ++c) acc[c] = 0.0;
+                for (int j0 = i & ~3; j0 < n; j0 += 4) {
+                    const uint4 a4 = *reinterpret_cast<const uint4*>(&s_aid[j0]);
+                    const uint32_t aj[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {                            // in event order: Counter += is a sequence of double adds
+                        const int j = j0 + e;
+                        if (aj[e] == ai && j >= i && j < n)
+                            for (int c = 0; c < NCV; ++c) acc[c] = __dadd_rn(acc[c], s_wc[c][j]);
+                    }
                 }
+                for (int c = 0; c < NCV; ++c) s_acc[c][i] = acc[c];
             }
         }
         __syncthreads();
@@ -823,8 +839,19 @@ __global__ __launch_bounds__(THREADS) void k_recency(RecencyArgs a) {
             for (int c = 0; c < NCV; ++c) {
                 const double wi = s_acc[c][i];
                 int rank = 0;
-                for (int r = 0; r < n; ++r)
-                    if (s_first[r] && (s_acc[c][r] > wi || (s_acc[c][r] == wi && r < i))) ++rank;
+#pragma unroll 2
+                for (int r0 = 0; r0 < n; r0 += 4) {
+                    const uint32_t f4 = *reinterpret_cast<const uint32_t*>(&s_first[r0]);
+                    const double2 w01 = *reinterpret_cast<const double2*>(&s_acc[c][r0]);
+                    const double2 w23 = *reinterpret_cast<const double2*>(&s_acc[c][r0 + 2]);
+                    const double wr[4] = {w01.x, w01.y, w23.x, w23.y};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = r0 + e;
+                        const bool fr = ((f4 >> (8 * e)) & 1u) != 0 && r < n;
+                        rank += (fr && (wr[e] > wi || (wr[e] == wi && r < i))) ? 1 : 0;
+                    }
+                }
                 const size_t o = (size_t)c * (size_t)a.n_events + (size_t)lo + (size_t)rank;
                 a.out_aid[o] = (int32_t)s_aid[i];
                 a.out_w[o] = wi;
